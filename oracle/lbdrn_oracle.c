@@ -1,0 +1,405 @@
+/*
+ * lbdrn_oracle.c -- CPU restatement of the LBDRN-MSIC per-image hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product (lbdrn-msic_amd/, bench.py's
+ * measured leg) may link, load or call this file; only tests/, the smoke check
+ * and bench.py's cpu_baseline leg use it, and only as the checker.
+ *
+ * Every function cites the reference lines (relative to /root/reference) it
+ * restates.  The arithmetic is written out so that it is reproducible bit for
+ * bit on any IEEE-754 machine: float32 everywhere the reference computes in
+ * float32, each dot product a k-ordered fmaf chain that starts from the bias
+ * (the order an f32 MFMA produces), sin/cos/exp as explicit polynomial
+ * kernels (coefficients: oracle/derive_coeffs.py).  torch's CPU sgemm order
+ * and vectorised sin are unspecified, so this file -- not torch -- defines
+ * the bit pattern the HIP path has to hit; tests/test_oracle_golden.py pins
+ * it to outputs of the imported reference modules within float tolerance.
+ *
+ * Build: gcc -O2 -fPIC -shared -ffp-contract=off -fno-fast-math (oracle/build.py)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- canonical math */
+
+static const float TWO_OVER_PI = 0x1.45f306p-1f;
+static const float PIO2_A = 0x1.921fb6p+0f, PIO2_B = -0x1.777a5cp-25f, PIO2_C = -0x1.ee59dap-50f;
+static const float SIN_C0 = -0x1.555556p-3f, SIN_C1 = 0x1.11110ep-7f, SIN_C2 = -0x1.a0133p-13f,
+                   SIN_C3 = 0x1.6d96dp-19f;
+static const float COS_C0 = -0x1.0p-1f, COS_C1 = 0x1.555556p-5f, COS_C2 = -0x1.6c16bap-10f,
+                   COS_C3 = 0x1.a0122ep-16f, COS_C4 = -0x1.245a26p-22f;
+static const float LOG2E = 0x1.715476p+0f, LN2_A = 0x1.62e43p-1f, LN2_B = -0x1.05c61p-29f;
+static const float EXP_C0 = 0x1.0p-1f, EXP_C1 = 0x1.5554d4p-3f, EXP_C2 = 0x1.5554ep-5f,
+                   EXP_C3 = 0x1.121588p-7f, EXP_C4 = 0x1.6d4f48p-10f;
+
+/* value of sin (quad even) or cos (quad odd) of the reduced argument, signed by quadrant */
+static inline float sincos_poly(float r, int quad)
+{
+    float s = r * r;
+    float ps = fmaf(fmaf(fmaf(SIN_C3, s, SIN_C2), s, SIN_C1), s, SIN_C0);
+    float sn = fmaf(r * s, ps, r);
+    float pc = fmaf(fmaf(fmaf(fmaf(COS_C4, s, COS_C3), s, COS_C2), s, COS_C1), s, COS_C0);
+    float cs = fmaf(s, pc, 1.0f);
+    float v = (quad & 1) ? cs : sn;
+    return (quad & 2) ? -v : v;
+}
+
+/* |x| > 2^16 or non-finite: reduce in float64 (two-piece pi/2) */
+static float sincos_big(float x, int shift)
+{
+    if (!(fabsf(x) < INFINITY)) return x - x;
+    double xd = (double)x;
+    double kd = rint(xd * 0x1.45f306dc9c883p-1);
+    double r = fma(-kd, 0x1.921fb54442d18p+0, xd);
+    r = fma(-kd, 0x1.1a62633145c07p-54, r);
+    double q4 = kd - 4.0 * floor(kd * 0.25);
+    return sincos_poly((float)r, (int)q4 + shift);
+}
+
+/* shift 0 -> sin(x), shift 1 -> cos(x) */
+static inline float canon_sincos(float x, int shift)
+{
+    if (!(fabsf(x) <= 65536.0f)) return sincos_big(x, shift);
+    float k = rintf(x * TWO_OVER_PI);
+    float r = fmaf(-k, PIO2_A, x);
+    r = fmaf(-k, PIO2_B, r);
+    r = fmaf(-k, PIO2_C, r);
+    return sincos_poly(r, (int)k + shift);
+}
+
+/* e^(-a), 0 <= a <= 86 */
+static inline float canon_exp_neg(float a)
+{
+    float x = -a;
+    float n = rintf(x * LOG2E);
+    float r = fmaf(-n, LN2_A, x);
+    r = fmaf(-n, LN2_B, r);
+    float e = fmaf(fmaf(fmaf(fmaf(EXP_C4, r, EXP_C3), r, EXP_C2), r, EXP_C1), r, EXP_C0);
+    float p = fmaf(r * r, e, r) + 1.0f;
+    int32_t bits;
+    memcpy(&bits, &p, 4);
+    bits += ((int32_t)n) << 23;
+    memcpy(&p, &bits, 4);
+    return p;
+}
+
+/* nn.Sigmoid: LBDRNmodel.py:75 */
+static inline float canon_sigmoid(float z)
+{
+    float a = fabsf(z);
+    a = (a > 86.0f) ? 86.0f : a; /* NaN stays NaN */
+    float t = canon_exp_neg(a);
+    float d = 1.0f + t;
+    return (z >= 0.0f) ? 1.0f / d : t / d;
+}
+
+float orc_sin(float x) { return canon_sincos(x, 0); }
+float orc_cos(float x) { return canon_sincos(x, 1); }
+float orc_sigmoid(float x) { return canon_sigmoid(x); }
+
+/* ---------------------------------------------------------------- a1: bit split */
+
+/* LBDRNdataset.py:95-101, 131.  img [C][H][W] u16 -> msb [C][H][W] u16 (value img>>K),
+ * labels [H*W][C] f32 = (img - (msb<<K)) / (2^K-1); returns max(msb) in *msb_max. */
+int orc_split_bits(const uint16_t *img, int C, int H, int W, int K, uint16_t *msb, float *labels,
+                   int *msb_max)
+{
+    if (K < 1 || K > 15) return -1;
+    const float denom = (float)((1 << K) - 1);
+    int mx = 0;
+    const int64_t HW = (int64_t)H * W;
+    for (int c = 0; c < C; ++c)
+        for (int64_t n = 0; n < HW; ++n) {
+            unsigned v = img[c * HW + n];
+            unsigned hi = v >> K;
+            unsigned lo = v - (hi << K);
+            if (msb) msb[c * HW + n] = (uint16_t)hi;
+            if (labels) labels[n * C + c] = (float)lo / denom;
+            if ((int)hi > mx) mx = (int)hi;
+        }
+    if (msb_max) *msb_max = mx;
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a2/a3: features */
+
+/* numpy.pad(mode='reflect') index map: LBDRNdataset.py:120-123 */
+static inline int reflect_idx(int i, int n)
+{
+    if (n == 1) return 0;
+    int period = 2 * (n - 1);
+    i %= period;
+    if (i < 0) i += period;
+    return (i < n) ? i : period - i;
+}
+
+typedef struct {
+    int C, H, W, D;
+    int msb_max;     /* divisor: MSB.max(), LBDRNdataset.py:120 / decode.py:93 */
+    int use_colors;  /* constants.py:11 */
+    int relative;    /* constants.py:14 */
+    int P;           /* positional features per axis: 0, 1 (coords) or 1+2*N_FREQ (embedding) */
+    const float *rowtab; /* [H][P]  ph-derived part, LBDRNdataset.py:108-118 */
+    const float *coltab; /* [W][P]  pw-derived part */
+} orc_feat_cfg;
+
+static int feat_dim(const orc_feat_cfg *g)
+{
+    int side = 2 * g->D + 1;
+    return 2 * g->P + (g->use_colors ? g->C * side * side : 0);
+}
+
+/* one feature row for pixel (y,x): layout [rowtab | coltab | c*(side^2)+dy*side+dx] */
+static void feat_row(const orc_feat_cfg *g, const uint16_t *msb, int y, int x, float *out)
+{
+    const int side = 2 * g->D + 1;
+    const int64_t HW = (int64_t)g->H * g->W;
+    const float mx = (float)g->msb_max;
+    int o = 0;
+    for (int p = 0; p < g->P; ++p) out[o++] = g->rowtab[(int64_t)y * g->P + p];
+    for (int p = 0; p < g->P; ++p) out[o++] = g->coltab[(int64_t)x * g->P + p];
+    if (!g->use_colors) return;
+    const int rel = g->relative && g->D > 0; /* LBDRNdataset.py:126 */
+    for (int c = 0; c < g->C; ++c) {
+        const uint16_t *pl = msb + c * HW;
+        float ctr = (float)pl[(int64_t)y * g->W + x] / mx;
+        for (int dy = 0; dy < side; ++dy) {
+            int yy = reflect_idx(y + dy - g->D, g->H);
+            for (int dx = 0; dx < side; ++dx) {
+                int xx = reflect_idx(x + dx - g->D, g->W);
+                float v = (float)pl[(int64_t)yy * g->W + xx] / mx;
+                out[o++] = rel ? v - ctr : v;
+            }
+        }
+    }
+}
+
+int orc_feature_dim(int C, int D, int use_colors, int P)
+{
+    orc_feat_cfg g = {C, 1, 1, D, 1, use_colors, 1, P, 0, 0};
+    return feat_dim(&g);
+}
+
+/* LBDRNdataset.py:104-130 (dup. decode.py:77-102).  idx == NULL: rows 0..n-1 in raster order. */
+int orc_features(const uint16_t *msb, int C, int H, int W, int D, int msb_max, int use_colors,
+                 int relative, int P, const float *rowtab, const float *coltab,
+                 const int64_t *idx, int64_t n, float *out)
+{
+    orc_feat_cfg g = {C, H, W, D, msb_max, use_colors, relative, P, rowtab, coltab};
+    const int F = feat_dim(&g);
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t pix = idx ? idx[i] : i;
+        if (pix < 0 || pix >= (int64_t)H * W) return -2;
+        feat_row(&g, msb, (int)(pix / W), (int)(pix % W), out + i * F);
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a5: forward */
+
+/* parameter vector in state_dict order (encode.py:124-128): for each hidden layer
+ * W[bc][in] then b[bc]; last layer W[C][bc], b[C]. */
+static int64_t param_count(int F, int bc, int C, int nl)
+{
+    int64_t n = 0;
+    for (int l = 0; l < nl; ++l) n += (int64_t)bc * (l ? bc : F) + bc;
+    return n + (int64_t)C * bc + C;
+}
+int64_t orc_param_count(int F, int bc, int C, int nl) { return param_count(F, bc, C, nl); }
+
+/* y[j] = b[j] then fmaf over k ascending: nn.Linear, LBDRNmodel.py:32,40 */
+static void linear_row(const float *Wt, const float *b, int nout, int nin, const float *x, float *z)
+{
+    for (int j = 0; j < nout; ++j) {
+        float acc = b[j];
+        const float *w = Wt + (int64_t)j * nin;
+        for (int k = 0; k < nin; ++k) acc = fmaf(x[k], w[k], acc);
+        z[j] = acc;
+    }
+}
+
+/* LBDRNmodel.py:79-82 for one row; zs (optional) receives the pre-activations of the hidden
+ * layers [nl][bc] and hs the activations, for the backward pass. */
+static void forward_row(const float *params, int F, int bc, int C, int nl, const float *x,
+                        float *y, float *zs, float *hs, float *scratch)
+{
+    const float *p = params;
+    const float *in = x;
+    int nin = F;
+    float *z = scratch, *h = scratch + bc;
+    for (int l = 0; l < nl; ++l) {
+        float *zl = zs ? zs + (int64_t)l * bc : z;
+        float *hl = hs ? hs + (int64_t)l * bc : ((l & 1) ? h + bc : h);
+        linear_row(p, p + (int64_t)bc * nin, bc, nin, in, zl);
+        for (int j = 0; j < bc; ++j) hl[j] = canon_sincos(30.0f * zl[j], 0); /* Sine: :12-13 */
+        p += (int64_t)bc * nin + bc;
+        in = hl;
+        nin = bc;
+    }
+    float zo[64];
+    float *zlast = (C <= 64) ? zo : (float *)malloc(sizeof(float) * C);
+    linear_row(p, p + (int64_t)C * nin, C, nin, in, zlast);
+    for (int c = 0; c < C; ++c) y[c] = canon_sigmoid(zlast[c]);
+    if (zlast != zo) free(zlast);
+}
+
+int orc_forward(const float *params, int F, int bc, int C, int nl, const float *x, int64_t B,
+                float *y)
+{
+    if (nl < 1) return -1;
+    float *scratch = (float *)malloc(sizeof(float) * 3 * bc);
+    for (int64_t i = 0; i < B; ++i)
+        forward_row(params, F, bc, C, nl, x + i * F, y + i * C, 0, 0, scratch);
+    free(scratch);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a11: apply + reconstruct */
+
+/* decode.py:73-134: features from the MSB plane, forward, r = round_half_even(y*(2^K-1)),
+ * out[c][y][x] = (msb<<K) + r.  y_out (optional) [H*W][C] receives the sigmoid outputs. */
+int orc_decode(const uint16_t *msb, int C, int H, int W, int K, int D, int msb_max,
+               int use_colors, int relative, int P, const float *rowtab, const float *coltab,
+               const float *params, int bc, int nl, uint16_t *out, float *y_out)
+{
+    orc_feat_cfg g = {C, H, W, D, msb_max, use_colors, relative, P, rowtab, coltab};
+    const int F = feat_dim(&g);
+    const float scale = (float)((1 << K) - 1);
+    const int64_t HW = (int64_t)H * W;
+    float *x = (float *)malloc(sizeof(float) * (F + C + 3 * bc));
+    float *y = x + F, *scratch = y + C;
+    for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx) {
+            int64_t n = (int64_t)yy * W + xx;
+            feat_row(&g, msb, yy, xx, x);
+            forward_row(params, F, bc, C, nl, x, y, 0, 0, scratch);
+            for (int c = 0; c < C; ++c) {
+                float r = rintf(y[c] * scale); /* torch.round: decode.py:131 */
+                float v = (float)((unsigned)msb[c * HW + n] << K) + r; /* :134 */
+                out[c * HW + n] = (uint16_t)rintf(v);
+                if (y_out) y_out[n * C + c] = y[c];
+            }
+        }
+    free(x);
+    return 0;
+}
+
+/* ---------------------------------------------------------------- a9: whole-image MSE */
+
+/* LBDRNperformance.py:18-21 over the evaluator's outputs (modified_ignite_engine.py:38-43):
+ * sum over all pixels and channels of (y - label)^2, accumulated in float64; the caller
+ * divides by H*W*C.  labels [H*W][C]. */
+double orc_eval_sse(const uint16_t *msb, const float *labels, int C, int H, int W, int D,
+                    int msb_max, int use_colors, int relative, int P, const float *rowtab,
+                    const float *coltab, const float *params, int bc, int nl)
+{
+    orc_feat_cfg g = {C, H, W, D, msb_max, use_colors, relative, P, rowtab, coltab};
+    const int F = feat_dim(&g);
+    float *x = (float *)malloc(sizeof(float) * (F + C + 3 * bc));
+    float *y = x + F, *scratch = y + C;
+    double sse = 0.0;
+    for (int yy = 0; yy < H; ++yy)
+        for (int xx = 0; xx < W; ++xx) {
+            int64_t n = (int64_t)yy * W + xx;
+            feat_row(&g, msb, yy, xx, x);
+            forward_row(params, F, bc, C, nl, x, y, 0, 0, scratch);
+            for (int c = 0; c < C; ++c) {
+                float d = y[c] - labels[n * C + c];
+                sse += (double)(d * d);
+            }
+        }
+    free(x);
+    return sse;
+}
+
+/* ---------------------------------------------------------------- a7/a8: loss, backward, Adam */
+
+/* One trainer update (modified_ignite_engine.py:18-27) on a given minibatch:
+ * forward, LBDRNLoss (LBDRNloss.py:8-11), autograd of LBDRNmodel.py:79-82, then torch Adam
+ * single-tensor math (torch/optim/adam.py: lerp_, mul_/addcmul_, addcdiv_) with defaults
+ * beta=(0.9,0.999), eps=1e-8 (encode.py:84).  Gradient sums run in float64 and are rounded to
+ * float32 once: the reference's sgemm order is unspecified, so this is the tolerance target
+ * (1e-5 relative), not a bit pattern.  step is the 1-based Adam step count.
+ * grads (optional) receives the float32 gradient vector; if apply_adam == 0 only loss/grads. */
+int orc_train_step(float *params, float *m, float *v, int F, int bc, int C, int nl,
+                   const float *x, const float *t, int B, double lr, int step, int apply_adam,
+                   double *loss_out, float *grads)
+{
+    const int64_t NP = param_count(F, bc, C, nl);
+    double *g = (double *)calloc(NP, sizeof(double));
+    float *zs = (float *)malloc(sizeof(float) * ((int64_t)2 * nl * bc + C + 3 * bc + 2 * bc));
+    float *hs = zs + (int64_t)nl * bc;
+    float *y = hs + (int64_t)nl * bc;
+    float *scratch = y + C;
+    float *dh = scratch + 3 * bc, *dz = dh + bc;
+    const float inv = 1.0f / ((float)B * (float)C);
+    double loss = 0.0;
+    /* per-layer parameter offsets */
+    int64_t *offW = (int64_t *)malloc(sizeof(int64_t) * (nl + 1));
+    int64_t o = 0;
+    for (int l = 0; l < nl; ++l) { offW[l] = o; o += (int64_t)bc * (l ? bc : F) + bc; }
+    offW[nl] = o;
+    for (int i = 0; i < B; ++i) {
+        const float *xi = x + (int64_t)i * F;
+        forward_row(params, F, bc, C, nl, xi, y, zs, hs, scratch);
+        /* loss and d(loss)/dz_last */
+        const float *Wl = params + offW[nl];
+        double *gWl = g + offW[nl], *gbl = gWl + (int64_t)C * bc;
+        const float *hlast = hs + (int64_t)(nl - 1) * bc;
+        for (int j = 0; j < bc; ++j) dh[j] = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            float d = y[c] - t[(int64_t)i * C + c];
+            loss += (double)(d * d);
+            float dy = 2.0f * d * inv;
+            float dzc = dy * (y[c] * (1.0f - y[c])); /* sigmoid backward */
+            gbl[c] += dzc;
+            for (int j = 0; j < bc; ++j) {
+                gWl[(int64_t)c * bc + j] += (double)dzc * hlast[j];
+                dh[j] = fmaf(dzc, Wl[(int64_t)c * bc + j], dh[j]);
+            }
+        }
+        for (int l = nl - 1; l >= 0; --l) {
+            const int nin = l ? bc : F;
+            const float *in = l ? hs + (int64_t)(l - 1) * bc : xi;
+            const float *Wc = params + offW[l];
+            double *gW = g + offW[l], *gb = gW + (int64_t)bc * nin;
+            const float *zl = zs + (int64_t)l * bc;
+            for (int j = 0; j < bc; ++j) {
+                /* d sin(30 z)/dz = cos(30 z) * 30 */
+                dz[j] = (dh[j] * canon_sincos(30.0f * zl[j], 1)) * 30.0f;
+                gb[j] += dz[j];
+                for (int k = 0; k < nin; ++k) gW[(int64_t)j * nin + k] += (double)dz[j] * in[k];
+            }
+            if (l) {
+                for (int k = 0; k < nin; ++k) {
+                    float a = 0.0f;
+                    for (int j = 0; j < bc; ++j) a = fmaf(dz[j], Wc[(int64_t)j * nin + k], a);
+                    dh[k] = a;
+                }
+            }
+        }
+    }
+    if (loss_out) *loss_out = loss / ((double)B * C);
+    if (grads) for (int64_t i = 0; i < NP; ++i) grads[i] = (float)g[i];
+    if (apply_adam) {
+        const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+        const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999);
+        const double bc1 = 1.0 - pow(0.9, step), bc2 = 1.0 - pow(0.999, step);
+        const float step_size = (float)(lr / bc1);
+        const float bc2s = (float)sqrt(bc2);
+        (void)b1;
+        for (int64_t i = 0; i < NP; ++i) {
+            float gi = (float)g[i];
+            m[i] = m[i] + w1 * (gi - m[i]);                 /* exp_avg.lerp_(grad, 1-beta1) */
+            v[i] = v[i] * b2 + w2 * (gi * gi);              /* mul_(beta2).addcmul_(g,g,1-beta2) */
+            float denom = sqrtf(v[i]) / bc2s + eps;
+            params[i] = params[i] + (-step_size) * (m[i] / denom); /* addcdiv_ */
+        }
+    }
+    free(offW);
+    free(zs);
+    free(g);
+    return 0;
+}
