@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Benchmark of the LBDRN per-image encode+decode hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic tile: the fused fit (bit split, 10 epochs of
+minibatch Adam with a whole-image evaluation after each, best-epoch selection), the 16-bit weight
+truncation the bitstream applies, and the fused apply (reconstruction).  Each rank owns its own
+tiles (images are independent fits): weak scaling, no data-path collective; RCCL
+carries only the max-over-ranks time and the per-image metric records.  Inputs are resident in HBM
+when the timed region starts; host work that belongs to the path (the permutations of
+torch.randperm order) is inside the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lbdrn-msic_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+SEED = 19920517  # ref encode.py:169
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--height", type=int, default=2048)
+    p.add_argument("--width", type=int, default=2048)
+    p.add_argument("--bands", type=int, default=8)
+    p.add_argument("-K", type=int, default=5)
+    p.add_argument("-D", type=int, default=2)
+    p.add_argument("-bc", type=int, default=64)
+    p.add_argument("-nl", type=int, default=2)
+    p.add_argument("-bs", type=int, default=8192)
+    p.add_argument("-e", "--epochs", type=int, default=10)
+    p.add_argument("--lr", type=float, default=1e-3)
+    p.add_argument("--path", choices=["auto", "generic", "mfma"], default="auto")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample", type=int, default=192, help="side of the CPU-baseline crop")
+    return p.parse_args()
+
+
+def one_image(codec, ops, img_d, a, path):
+    """encode (fit) + weight truncation + decode (apply) for one HBM-resident tile."""
+    torch.manual_seed(SEED)  # every encode.py invocation seeds itself (ref encode.py:200-205)
+    fit = codec.fit_device(img_d, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, path=path)
+    params = codec.truncate_device(fit.best_params, 16)
+    rec = codec.apply_device(fit.geom, fit.net, fit.msb, params, path=path)
+    return fit, rec
+
+
+def flops_per_pixel(F, bc, C, nl):
+    fwd = 2 * (F * bc + (nl - 1) * bc * bc + bc * C)
+    bwd = fwd + 2 * ((nl - 1) * bc * bc + bc * C)   # dW (same as fwd) + dX of every layer but the first
+    return fwd, fwd + bwd
+
+
+def event_time_ms(fn, stream, repeat=1):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(stream)
+    for _ in range(repeat):
+        fn()
+    e.record(stream)
+    e.synchronize()
+    return s.elapsed_time(e) / repeat
+
+
+def roofline_probe(codec, ops, fit, img_d, a, path):
+    """HIP-event timing, on the launch stream, of the kernels the run is made of (same process, same
+    tile, right after the timed region).  Reported for the dominant one."""
+    stream = torch.cuda.current_stream()
+    geom, net = fit.geom, fit.net
+    N = geom.H * geom.W
+    fwd, step = flops_per_pixel(geom.F, net.bc, net.C, net.nl)
+    ws = ops.ApplyWorkspace(geom, net, img_d.device)
+    p = fit.best_params
+    ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws)
+    t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws), stream, 3)
+    # one training epoch on scratch weights
+    perm = torch.randperm(N, device=img_d.device)
+    pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device)
+    t_train = event_time_ms(lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0,
+                                                    1e-6, None, path, tws), stream, 1)
+    nsteps = (N + a.bs - 1) // a.bs
+    peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
+    eval_tf = fwd * N / (t_eval * 1e-3) / 1e12
+    train_tf = step * N / (t_train * 1e-3) / 1e12
+    dominant_train = a.epochs * t_train >= a.epochs * t_eval
+    ach = train_tf if dominant_train else eval_tf
+    return {
+        "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(ach / peak, 4), "traffic": None,
+        "kernel": "train step (gather+fwd+bwd+Adam, per 8192-row minibatch)" if dominant_train
+                  else "fused apply (gather+fwd+SSE)",
+        "train_step_us": round(t_train * 1e3 / nsteps, 2), "train_tflops": round(train_tf, 3),
+        "eval_pass_ms": round(t_eval, 3), "eval_tflops": round(eval_tf, 3),
+        "hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1),
+    }
+
+
+def cpu_baseline(a):
+    """The torch-CPU restatement of the reference loop (oracle/torch_port.py, form A: map-style
+    dataset + DataLoader + per-step update + concatenating whole-image metric) on a crop of the same
+    synthetic tile, sized for ~10-30 s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_port as TP
+    from lbdrn_hip.synth import synthetic_tile
+    side = a.cpu_sample
+    img = synthetic_tile(0, a.bands, a.height, a.width)[:, :side, :side].copy()
+    torch.manual_seed(SEED)
+    t0 = time.time()
+    r = TP.fit(img, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, faithful=True)
+    t_enc = time.time() - t0
+    t0 = time.time()
+    TP.apply(r["msb"], r["params"], a.K, a.D, a.bc, a.nl)
+    t_dec = time.time() - t0
+    return {"value": round(side * side / (t_enc + t_dec) / 1e6, 6), "unit": "Mpixels/s",
+            "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{side}x{side}x{a.bands} crop of tile 0, full recipe (e={a.epochs}, bs={a.bs}), "
+                      f"DataLoader(num_workers=0) + per-step Adam + concatenating eval metric; "
+                      f"encode {t_enc:.1f}s decode {t_dec:.1f}s; feature build excluded from neither"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print("bench.py needs a GPU (liblbdrn_hip has no CPU path)", file=sys.stderr)
+        return 2
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from lbdrn_hip import codec, ops
+    from lbdrn_hip.synth import synthetic_tile
+    path = {"auto": ops._lib.PATH_AUTO, "generic": ops._lib.PATH_GENERIC, "mfma": ops._lib.PATH_MFMA}[a.path]
+
+    # tiles of this rank, resident in HBM before the clock starts (image index unique per rank/step)
+    total = a.warmup + a.steps
+    tiles = [ops.to_device_u16(synthetic_tile(rank * total + i, a.bands, a.height, a.width), dev)
+             for i in range(total)]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_image(codec, ops, tiles[i], a, path)
+    barrier()
+    t0 = time.perf_counter()
+    last = None
+    records = []
+    for i in range(a.warmup, total):
+        fit, rec = one_image(codec, ops, tiles[i], a, path)
+        last = (fit, rec, tiles[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # per-image metric record of the last tile (after the clock): MSE / PSNR of the reconstruction
+    fit, rec, img_d = last
+    diff = (img_d.view(torch.int16).to(torch.int32) & 0xFFFF).float() - (rec.to(torch.int32) & 0xFFFF).float()
+    mse = float((diff * diff).mean().item())
+    rec_t = torch.tensor([rank, mse, float(fit.mse_log[:, 0].min().item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        gathered = [torch.zeros_like(rec_t) for _ in range(world)]
+        dist.all_gather(gathered, rec_t)   # the only data the ranks exchange
+        records = [g.tolist() for g in gathered]
+    else:
+        records = [rec_t.tolist()]
+
+    if rank == 0:
+        px = a.height * a.width
+        value = px * a.steps * world / elapsed / 1e6
+        out = {
+            "metric": "Mpixels/s encode+decode (and bpp/PSNR parity) on D2/K5/bc64/nl2",
+            "value": round(value, 4), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {a.bands}-band {a.height}x{a.width} uint16 tile per step, "
+                                   f"K={a.K} D={a.D} bc={a.bc} nl={a.nl} bs={a.bs} e={a.epochs} "
+                                   f"(BASELINE.json configs[1]); encode fit + 16-bit weight truncation + decode",
+                       "tiles_per_gpu": a.steps, "parallelism": f"image-sharded x{world}", "path": a.path},
+            "recon_mse_last_tile": round(mse, 4),
+            "recon_psnr_last_tile": round(10 * np.log10(10000 ** 2 / max(mse, 1e-12)), 3),
+            "records": records,
+        }
+        out["roofline"] = roofline_probe(codec, ops, fit, img_d, a, path)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

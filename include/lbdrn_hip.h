@@ -1,0 +1,135 @@
+/*
+ * lbdrn_hip.h -- C ABI of liblbdrn_hip.so, the MI355X (gfx950) implementation of the
+ * LBDRN-MSIC per-image fit/apply hot path.
+ *
+ * The reference (/root/reference, pure Python) has no FFI of its own; its boundary is the
+ * Python surface encode.py / decode.py / LBDRNmodel.py / LBDRNdataset.py.  Each entry point
+ * below names the reference lines whose arithmetic it replaces; the Python host code in
+ * lbdrn-msic_amd/ binds them with ctypes (lbdrn_hip/_lib.py) and INTEGRATION.md shows the stub
+ * a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C, no exceptions: every call returns 0 on success or a negative lbdrn_status;
+ *    lbdrn_last_error() returns a per-thread message for the last failure.
+ *  - all data pointers are caller-owned DEVICE pointers (HBM); the library never frees or
+ *    retains them.  Scalars and the two config structs are passed by value / host pointer.
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
+ *    stream) and re-entrant; there is no global mutable state besides the error string.
+ *  - there is no CPU path: without a gfx950 device every compute call returns LBDRN_E_DEVICE.
+ *  - images are channel-planar [C][H][W] uint16, as GDAL's ReadAsArray() returns them
+ *    (ref LBDRNdataset.py:93-94); feature / label matrices are row-major [N][F] / [N][C]
+ *    float32, row n = pixel y*W+x (ref LBDRNdataset.py:129-131).
+ */
+#ifndef LBDRN_HIP_H
+#define LBDRN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBDRN_ABI_VERSION 1
+
+typedef enum lbdrn_status {
+    LBDRN_OK = 0,
+    LBDRN_E_ARG = -1,     /* invalid argument (shape, range, null pointer) */
+    LBDRN_E_DEVICE = -2,  /* no usable gfx950 device / HIP runtime error */
+    LBDRN_E_UNSUPPORTED = -3,
+    LBDRN_E_WORKSPACE = -4 /* workspace too small */
+} lbdrn_status;
+
+/* Image + feature geometry: constants.py:3-14 plus the per-image numbers process() derives. */
+typedef struct lbdrn_geom {
+    int32_t C, H, W;      /* bands, rows, columns */
+    int32_t K;            /* low bits dropped (encode.py:178) */
+    int32_t D;            /* neighbourhood radius, window (2D+1)^2 (encode.py:184) */
+    int32_t msb_max;      /* MSB.max(): LBDRNdataset.py:120, decode.py:93 */
+    int32_t use_colors;   /* constants.py:11 */
+    int32_t relative;     /* constants.py:14 */
+    int32_t P;            /* positional features per axis: 0, 1 or 1+2*N_FREQ (constants.py:3-8) */
+    int32_t reserved;
+    const float *rowtab;  /* device [H][P]: ph-derived features (LBDRNdataset.py:108-118) */
+    const float *coltab;  /* device [W][P]: pw-derived features */
+} lbdrn_geom;
+
+/* LBDRNModel(dim_in=F, dim_hidden=bc, dim_out=C, num_layers=nl): LBDRNmodel.py:58-77.
+ * Parameters travel as one float32 vector in state_dict order (encode.py:124-128):
+ * for l in 0..nl-1: W_l[bc][in_l], b_l[bc];  then W_last[C][bc], b_last[C]. */
+typedef struct lbdrn_net {
+    int32_t F, bc, C, nl;
+} lbdrn_net;
+
+const char *lbdrn_last_error(void);
+int lbdrn_abi_version(void);
+/* 0 if a gfx950 device is present and usable, else LBDRN_E_DEVICE. */
+int lbdrn_device_check(void);
+int64_t lbdrn_param_count(const lbdrn_net *net);
+int32_t lbdrn_feature_dim(const lbdrn_geom *g);
+
+/* a1 -- LBDRNdataset.py:95-101: msb = img >> K (uint16 plane, same layout) and the running
+ * maximum of msb into *msb_max (device int32, must be zeroed by the caller or hold a previous
+ * maximum).  msb may be NULL (max only). */
+int lbdrn_split_bits(const uint16_t *img, int32_t C, int32_t H, int32_t W, int32_t K,
+                     uint16_t *msb, int32_t *msb_max, void *stream);
+
+/* a1 -- LBDRNdataset.py:96-97,131: labels[i][c] = float(img - (msb<<K)) / (2^K-1) for the pixels
+ * idx[0..n) (int64 device indices) or, when idx is NULL, for pixels 0..n-1 in raster order. */
+int lbdrn_labels(const uint16_t *img, int32_t C, int32_t H, int32_t W, int32_t K,
+                 const int64_t *idx, int64_t n, float *labels, void *stream);
+
+/* a2/a3 -- LBDRNdataset.py:104-130 (dup. decode.py:77-102): feature rows for idx[0..n) or raster
+ * order.  msb is the [C][H][W] uint16 MSB plane. */
+int lbdrn_features(const lbdrn_geom *g, const uint16_t *msb, const int64_t *idx, int64_t n,
+                   float *features, void *stream);
+
+/* a5 -- LBDRNModel.forward, LBDRNmodel.py:79-82: y[B][C] = sigmoid(W_last sin(30(...)) + b).
+ * workspace: device scratch of lbdrn_forward_workspace(net, B) bytes. */
+size_t lbdrn_forward_workspace(const lbdrn_net *net, int64_t B);
+int lbdrn_forward(const lbdrn_net *net, const float *params, const float *x, int64_t B, float *y,
+                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* a2+a5+a11 -- decode.py:73-134 in one pass: features from the MSB plane, forward,
+ * r = round_half_even(y*(2^K-1)), out = (msb<<K) + r as uint16 [C][H][W].
+ * y_out (optional, may be NULL) receives the sigmoid outputs [H*W][C].
+ * flags: LBDRN_PATH_AUTO picks the MFMA kernel when the shape supports it. */
+#define LBDRN_PATH_AUTO 0
+#define LBDRN_PATH_GENERIC 1 /* tiled f32 FMA kernels, any shape */
+#define LBDRN_PATH_MFMA 2    /* fused MFMA kernel; LBDRN_E_UNSUPPORTED if the shape does not fit */
+size_t lbdrn_apply_workspace(const lbdrn_geom *g, const lbdrn_net *net);
+int lbdrn_decode_fused(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *msb,
+                       const float *params, uint16_t *out, float *y_out, void *workspace,
+                       size_t workspace_bytes, int32_t path, void *stream);
+
+/* a9 -- evaluator + LBDRNPerformance (modified_ignite_engine.py:38-43, LBDRNperformance.py:18-21):
+ * *sse (device float64) = sum over all pixels and bands of (y - label)^2, fixed summation order
+ * (bitwise reproducible).  img is the original [C][H][W] image the labels derive from. */
+int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
+                   const uint16_t *msb, const float *params, double *sse, void *workspace,
+                   size_t workspace_bytes, int32_t path, void *stream);
+
+/* a4+a5+a7+a8 -- one trainer epoch (encode.py:69-70,157; modified_ignite_engine.py:18-27;
+ * torch.optim.Adam defaults, encode.py:84): for each minibatch perm[s*bs .. min((s+1)*bs,n))
+ * of pixel indices: gather features and labels, forward, MSE loss, backward, Adam update of
+ * params/exp_avg/exp_avg_sq in place.  adam_step0 = number of Adam steps already taken;
+ * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
+ * short (no drop_last, encode.py:69). */
+size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
+int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
+                      const uint16_t *msb, const int64_t *perm, int64_t n, int32_t batch_size,
+                      float *params, float *exp_avg, float *exp_avg_sq, int64_t adam_step0,
+                      double lr, float *losses, void *workspace, size_t workspace_bytes,
+                      int32_t path, void *stream);
+
+/* a7/a8 building block exposed for teacher-forced parity tests: one update on an explicit
+ * minibatch x[B][F], t[B][C]; grads (optional) receives d(loss)/d(params). */
+int lbdrn_train_step(const lbdrn_net *net, const float *x, const float *t, int32_t B,
+                     float *params, float *exp_avg, float *exp_avg_sq, int64_t adam_step,
+                     double lr, int32_t apply_adam, float *loss, float *grads, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBDRN_HIP_H */

@@ -1,0 +1,9 @@
+"""Feature switches shared by encoder and decoder (they are NOT stored in the bitstream, so both
+sides must run with the same values; same names and defaults as ref constants.py:3-14)."""
+
+USE_COORDINATES = False   # prepend normalised (row, col) coordinates
+EMBEDDING = False         # ... expanded by sin/cos of SIGMA**j * pi * coord, j < N_FREQ
+SIGMA = 1.4
+N_FREQ = 12
+USE_COLORS = True         # (2D+1)^2 neighbourhood of normalised high bits per band
+RELATIVE = True           # subtract the centre pixel from its neighbourhood

@@ -1,0 +1,446 @@
+// Fused apply kernel for gfx950: neighbourhood gather + normalise + nl x (Linear -> sin(30 z)) +
+// Linear -> sigmoid, then either integer reconstruction (decode.py:122-134) or the squared error
+// against the labels (LBDRNperformance.py:18-21), in ONE pass over the image with no feature
+// matrix in HBM (the reference materialises [N,F] float32 = 3.36 GB at 2048^2x8, D=2).
+//
+// Mapping to CDNA4
+//  * one wave = one 32-pixel row segment; every layer is computed transposed,
+//    H^T[neuron][pixel] = W[neuron][k] * X^T[k][pixel], on v_mfma_f32_32x32x2_f32: A = weights
+//    (one VGPR), B = inputs (one VGPR), accumulator tile = 32 neurons x 32 pixels (16 VGPRs).
+//  * an f32 MFMA is a k-ordered fmaf chain seeded by the C operand, so seeding C with the bias
+//    and walking k = 0,1,2,... reproduces the generic kernels / the oracle bit for bit.
+//  * the accumulator layout (row = (r&3)+8(r>>2)+4(lane>>5), col = lane&31) is turned into the
+//    next layer's B operand without any data movement: tile row i is assigned neuron
+//    pi(i) = 2*((i&3)+4*(i>>3)) + ((i>>2)&1), so register r of lane-half h holds neuron 2r+h --
+//    exactly the k = 2s+h the next MFMA step s consumes from that lane.  The permutation is
+//    applied once when the weights are packed into "fragment order".
+//  * weights (76 KB for F=200, bc=64) live in LDS in fragment order, so every A operand is one
+//    conflict-free ds_read_b64; the D-ring of normalised MSB values is staged per 16x64 tile in
+//    channel-planar LDS (conflict-free for 32 consecutive pixels) with reflect padding applied.
+//  * 8 waves per CU (2 per SIMD): one wave's sin() VALU work overlaps the other's MFMAs.
+#include "common.hpp"
+#include "lbdrn_math.hpp"
+
+namespace lbdrn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int APPLY_WAVES = 8;
+constexpr int APPLY_THREADS = APPLY_WAVES * 64;
+constexpr int TILE_W = 64;
+
+// tile row i of a hidden accumulator tile carries neuron pi(i) (+32*tile)
+__host__ __device__ inline int tile_row_to_neuron(int i)
+{
+    return 2 * ((i & 3) + 4 * (i >> 3)) + ((i >> 2) & 1);
+}
+// accumulator register r of lane-half h is tile row:
+__host__ __device__ inline int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct ApplyPlan {
+    int NT;          // hidden tiles = bc/32
+    int S0;          // MFMA steps of layer 0: P positional + colour steps padded to a multiple of 4
+                     // (pad steps carry zero weights: fmaf(0, finite, acc) == acc)
+    int TH;          // tile rows
+    int SH, SW;      // staged rows / pitch = TH+2D, TILE_W+2D
+    int ncolor;      // colour features = F - 2P
+    // float offsets inside the packed buffer == inside LDS
+    int off_w0, off_wh, off_wl, off_bh, off_bl, pack_floats;
+    // further LDS regions (float offsets)
+    int off_ktab, off_rowt, off_colt, off_tile, lds_floats;
+    int tiles_x, tiles_y;
+};
+
+static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p)
+{
+    if (net.bc % 32 != 0 || net.bc < 32 || net.bc > 128) return false;
+    if (net.C > 32 || net.nl < 1 || net.nl > 15) return false;
+    ApplyPlan q;
+    q.NT = net.bc / 32;
+    q.ncolor = net.F - 2 * g.P;
+    if (q.ncolor < 0) return false;
+    q.S0 = g.P + ((q.ncolor + 1) / 2 + 3) / 4 * 4;
+    const int half = net.bc / 2;
+    int o = 0;
+    q.off_w0 = o; o += q.S0 * 64 * q.NT;
+    q.off_wh = o; o += (net.nl - 1) * half * 64 * q.NT;
+    q.off_wl = o; o += half * 64;
+    q.off_bh = o; o += net.nl * q.NT * 32;
+    q.off_bl = o; o += 32;
+    q.pack_floats = o;
+    q.off_ktab = o; o += 2 * 2 * (q.S0 - g.P) + 2;
+    q.SW = TILE_W + 2 * g.D;
+    const int fixed = o;
+    int th = 16;
+    for (;; th >>= 1) {
+        if (th == 0) return false;
+        q.TH = th;
+        q.SH = th + 2 * g.D;
+        o = fixed;
+        q.off_rowt = o; o += th * g.P;
+        q.off_colt = o; o += TILE_W * g.P;
+        q.off_tile = o; o += (g.use_colors ? g.C * q.SH * q.SW : 0);
+        q.lds_floats = o;
+        if ((size_t)o * 4 <= 160 * 1024) break;
+    }
+    q.tiles_x = (g.W + TILE_W - 1) / TILE_W;
+    q.tiles_y = (g.H + q.TH - 1) / q.TH;
+    *p = q;
+    return true;
+}
+
+bool mfma_apply_supported(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    ApplyPlan p;
+    return make_plan(g, net, &p);
+}
+
+constexpr int MFMA_PARTIALS = 1024;
+
+size_t mfma_apply_workspace(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    ApplyPlan p;
+    if (!make_plan(g, net, &p)) return 0;
+    return align_up((size_t)p.pack_floats * 4, 256) + align_up(MFMA_PARTIALS * sizeof(double), 256);
+}
+
+// ------------------------------------------------------------------ weight packing
+
+// params (state_dict order) -> fragment order; one thread per packed float
+__global__ void __launch_bounds__(256)
+    k_pack_apply(const float* __restrict__ params, lbdrn_net net, ApplyPlan p, float* __restrict__ out)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.pack_floats) return;
+    const int NT = p.NT, half = net.bc / 2;
+    float v = 0.0f;
+    if (e < p.off_wh) {  // layer 0: [S0][64][NT]
+        int t = e % NT, lane = (e / NT) % 64, s = e / (NT * 64);
+        int k = 2 * s + (lane >> 5);
+        int neuron = tile_row_to_neuron(lane & 31) + 32 * t;
+        if (k < net.F) v = params[(int64_t)neuron * net.F + k];
+    } else if (e < p.off_wl) {  // hidden layers 1..nl-1: [l-1][half][64][NT]
+        int q = e - p.off_wh;
+        int t = q % NT, lane = (q / NT) % 64, s = (q / (NT * 64)) % half, l = 1 + q / (NT * 64 * half);
+        int k = 2 * s + (lane >> 5);
+        int neuron = tile_row_to_neuron(lane & 31) + 32 * t;
+        int64_t base = (int64_t)net.bc * net.F + net.bc + (int64_t)(l - 1) * ((int64_t)net.bc * net.bc + net.bc);
+        v = params[base + (int64_t)neuron * net.bc + k];
+    } else if (e < p.off_bh) {  // last layer: [half][64], rows = channels (identity order)
+        int q = e - p.off_wl;
+        int lane = q % 64, s = q / 64;
+        int k = 2 * s + (lane >> 5), ch = lane & 31;
+        int64_t base = (int64_t)net.bc * net.F + net.bc + (int64_t)(net.nl - 1) * ((int64_t)net.bc * net.bc + net.bc);
+        if (ch < net.C) v = params[base + (int64_t)ch * net.bc + k];
+    } else if (e < p.off_bl) {  // hidden biases: [l][t][h][16]
+        int q = e - p.off_bh;
+        int r = q % 16, h = (q / 16) % 2, t = (q / 32) % NT, l = q / (32 * NT);
+        int neuron = 2 * r + h + 32 * t;
+        int64_t wbase = l == 0 ? 0 : (int64_t)net.bc * net.F + net.bc + (int64_t)(l - 1) * ((int64_t)net.bc * net.bc + net.bc);
+        int64_t nin = l == 0 ? net.F : net.bc;
+        v = params[wbase + (int64_t)net.bc * nin + neuron];
+    } else {  // last bias: [h][16]
+        int q = e - p.off_bl;
+        int r = q % 16, h = q / 16;
+        int ch = acc_row(r, h);
+        int64_t base = (int64_t)net.bc * net.F + net.bc + (int64_t)(net.nl - 1) * ((int64_t)net.bc * net.bc + net.bc);
+        if (ch < net.C) v = params[base + (int64_t)net.C * net.bc + ch];
+    }
+    out[e] = v;
+}
+
+// ------------------------------------------------------------------ the fused kernel
+
+enum ApplyMode { MODE_DECODE = 0, MODE_EVAL = 1 };
+
+struct ApplyArgs {
+    lbdrn_geom g;
+    lbdrn_net net;
+    ApplyPlan p;
+    const float* packed;
+    const uint16_t* msb;
+    const uint16_t* img;  // EVAL: original image (labels)
+    uint16_t* out;        // DECODE
+    float* y_out;         // DECODE, optional
+    double* partial;      // EVAL: [gridDim.x]
+};
+
+template <int NT>
+__device__ __forceinline__ void load_a(const float* w, int idx, float (&a)[NT])
+{
+    if constexpr (NT == 1) {
+        a[0] = w[idx];
+    } else if constexpr (NT == 2) {
+        float2 v = *reinterpret_cast<const float2*>(w + (size_t)idx * 2);
+        a[0] = v.x; a[1] = v.y;
+    } else {
+        float4 v = *reinterpret_cast<const float4*>(w + (size_t)idx * 4);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    }
+}
+
+template <int NT, int MODE>
+__global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const lbdrn_geom& g = A.g;
+    const ApplyPlan& p = A.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int half = A.net.bc / 2;
+    const int P = g.P, D = g.D, C = g.C;
+
+    // ---- once per workgroup: weights (fragment order) and the colour offset table into LDS
+    for (int e = tid * 4; e < p.pack_floats; e += APPLY_THREADS * 4) {
+        if (e + 3 < p.pack_floats) {
+            *reinterpret_cast<float4*>(lds + e) = *reinterpret_cast<const float4*>(A.packed + e);
+        } else {
+            for (int q = e; q < p.pack_floats; ++q) lds[q] = A.packed[q];
+        }
+    }
+    int* ktab = reinterpret_cast<int*>(lds + p.off_ktab);
+    {
+        const int side = 2 * D + 1, plane = p.SH * p.SW;
+        for (int k = tid; k < 2 * (p.S0 - P) + 1; k += APPLY_THREADS) {
+            int kk = min(k, p.ncolor - 1);  // pad entries repeat the last feature (their weight is 0)
+            kk = max(kk, 0);
+            int c = kk / (side * side), r = kk - c * side * side;
+            int dy = r / side, dx = r - dy * side;
+            ktab[2 * k] = c * plane + (dy - D) * p.SW + (dx - D);
+            ktab[2 * k + 1] = c * plane;
+        }
+    }
+    const float* w0 = lds + p.off_w0;
+    const float* wh = lds + p.off_wh;
+    const float* wl = lds + p.off_wl;
+    const float* bh = lds + p.off_bh;
+    const float* bl = lds + p.off_bl;
+    float* rowt = lds + p.off_rowt;
+    float* colt = lds + p.off_colt;
+    float* tile = lds + p.off_tile;
+    const bool rel = g.relative && D > 0;
+    const float maxf = (float)g.msb_max;
+    const int64_t HW = (int64_t)g.H * g.W;
+    const float scale = (float)((1 << g.K) - 1);
+    const int lmask = (1 << g.K) - 1;
+    double sse = 0.0;
+
+    const int ntiles = p.tiles_x * p.tiles_y;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+        const int y0 = ty * p.TH, x0 = tx * TILE_W;
+        __syncthreads();  // previous tile fully consumed (and the weight copy landed)
+        // ---- stage the (TH+2D) x (64+2D) ring: p = float(msb)/max, reflect-padded (LBDRNdataset.py:120-123)
+        if (g.use_colors) {
+            const int plane = p.SH * p.SW, total = C * plane;
+            for (int e = tid; e < total; e += APPLY_THREADS) {
+                int c = e / plane, r = e - c * plane;
+                int sy = r / p.SW, sx = r - sy * p.SW;
+                int yy = reflect_idx(y0 + sy - D, g.H), xx = reflect_idx(x0 + sx - D, g.W);
+                tile[e] = (float)A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx] / maxf;
+            }
+        }
+        for (int e = tid; e < p.TH * P; e += APPLY_THREADS) {
+            int yy = min(y0 + e / P, g.H - 1);
+            rowt[e] = g.rowtab[(int64_t)yy * P + e % P];
+        }
+        for (int e = tid; e < TILE_W * P; e += APPLY_THREADS) {
+            int xx = min(x0 + e / P, g.W - 1);
+            colt[e] = g.coltab[(int64_t)xx * P + e % P];
+        }
+        __syncthreads();
+
+        const int nseg = p.TH * (TILE_W / 32);
+        for (int seg = wave; seg < nseg; seg += APPLY_WAVES) {
+            const int ly = seg / (TILE_W / 32), lx = (seg % (TILE_W / 32)) * 32;
+            const int pixbase = (ly + D) * p.SW + (lx + j + D);
+            f32x16 acc[NT];
+            f32x16 hid[NT];
+            // ---- layer 0: C operand = bias, then k = 0..F-1 in order
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    float4 b4 = *reinterpret_cast<const float4*>(bh + (tt * 2 + h) * 16 + q4 * 4);
+                    acc[tt][q4 * 4 + 0] = b4.x; acc[tt][q4 * 4 + 1] = b4.y;
+                    acc[tt][q4 * 4 + 2] = b4.z; acc[tt][q4 * 4 + 3] = b4.w;
+                }
+            for (int s = 0; s < P; ++s) {  // positional features, k = 2s+h < 2P
+                int k = 2 * s + h;
+                float b = (k < P) ? rowt[ly * P + k] : colt[(lx + j) * P + (k - P)];
+                float a[NT];
+                load_a<NT>(w0, s * 64 + lane, a);
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], b, acc[tt], 0, 0, 0);
+            }
+            for (int s4 = P; s4 < p.S0; s4 += 4) {  // colour features, four MFMA steps per trip
+                float bq[4];
+                float aq[4][NT];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int kk = 2 * (s4 + u - P) + h;
+                    int2 e = *reinterpret_cast<const int2*>(ktab + 2 * kk);
+                    float nb = tile[pixbase + e.x];
+                    float ct = tile[pixbase + e.y];
+                    bq[u] = rel ? nb - ct : nb;  // minus centre, LBDRNdataset.py:126-128
+                    load_a<NT>(w0, (s4 + u) * 64 + lane, aq[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][tt], bq[u], acc[tt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hid[tt][r] = siren_act(acc[tt][r]);
+            // ---- hidden layers 1..nl-1: B operand = previous activations, straight from registers
+            for (int l = 1; l < A.net.nl; ++l) {
+                const float* wlayer = wh + (size_t)(l - 1) * half * 64 * NT;
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        float4 b4 = *reinterpret_cast<const float4*>(bh + ((l * NT + tt) * 2 + h) * 16 + q4 * 4);
+                        acc[tt][q4 * 4 + 0] = b4.x; acc[tt][q4 * 4 + 1] = b4.y;
+                        acc[tt][q4 * 4 + 2] = b4.z; acc[tt][q4 * 4 + 3] = b4.w;
+                    }
+#pragma unroll
+                for (int s = 0; s < NT * 16; ++s) {
+                    float b = hid[s / 16][s % 16];
+                    float a[NT];
+                    load_a<NT>(wlayer, s * 64 + lane, a);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], b, acc[tt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hid[tt][r] = siren_act(acc[tt][r]);
+            }
+            // ---- last layer: rows = channels
+            f32x16 o;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                float4 b4 = *reinterpret_cast<const float4*>(bl + h * 16 + q4 * 4);
+                o[q4 * 4 + 0] = b4.x; o[q4 * 4 + 1] = b4.y; o[q4 * 4 + 2] = b4.z; o[q4 * 4 + 3] = b4.w;
+            }
+#pragma unroll
+            for (int s = 0; s < NT * 16; ++s) {
+                float b = hid[s / 16][s % 16];
+                float a = wl[s * 64 + lane];
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, o, 0, 0, 0);
+            }
+            // ---- epilogue
+            const int yy = y0 + ly, xx = x0 + lx + j;
+            const bool inside = yy < g.H && xx < g.W;
+            const int64_t pix = (int64_t)yy * g.W + xx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = acc_row(r, h);
+                if (ch < C && inside) {
+                    float yv = canon_sigmoid(o[r]);
+                    if (MODE == MODE_DECODE) {
+                        float rr = __builtin_rintf(yv * scale);  // torch.round, decode.py:131
+                        int base = (int)A.msb[(int64_t)ch * HW + pix] << g.K;  // decode.py:134
+                        A.out[(int64_t)ch * HW + pix] = (uint16_t)(base + (int)rr);
+                        if (A.y_out) A.y_out[pix * C + ch] = yv;
+                    } else {
+                        float lab = (float)((int)A.img[(int64_t)ch * HW + pix] & lmask) / scale;
+                        float d = yv - lab;
+                        sse += (double)(d * d);
+                    }
+                }
+            }
+        }
+    }
+    if (MODE == MODE_EVAL) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(lds);  // weights no longer needed
+        red[tid] = sse;
+        __syncthreads();
+        for (int o2 = APPLY_THREADS / 2; o2 > 0; o2 >>= 1) {
+            if (tid < o2) red[tid] += red[tid + o2];
+            __syncthreads();
+        }
+        if (tid == 0) A.partial[blockIdx.x] = red[0];
+    }
+}
+
+__global__ void k_sum_partials_mfma(const double* __restrict__ partial, int n, double* dst)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *dst = s;
+}
+
+template <int NT, int MODE>
+static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s)
+{
+    const size_t lds_bytes = (size_t)A.p.lds_floats * 4;
+    auto kern = k_apply_mfma<NT, MODE>;
+    LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    kern<<<grid, APPLY_THREADS, lds_bytes, s>>>(A);
+    LBDRN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const uint16_t* img,
+                     const uint16_t* msb, const float* params, uint16_t* out, float* y_out,
+                     double* sse, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    ApplyArgs A;
+    if (!make_plan(g, net, &A.p)) {
+        set_error("shape not supported by the MFMA apply kernel");
+        return LBDRN_E_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < mfma_apply_workspace(g, net)) {
+        set_error("apply workspace too small: %zu < %zu", ws_bytes, mfma_apply_workspace(g, net));
+        return LBDRN_E_WORKSPACE;
+    }
+    float* packed = (float*)ws;
+    double* partial = (double*)((char*)ws + align_up((size_t)A.p.pack_floats * 4, 256));
+    k_pack_apply<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, packed);
+    LBDRN_LAUNCH_CHECK();
+    A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
+    A.partial = partial;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int grid = std::min(std::min(A.p.tiles_x * A.p.tiles_y, cus), MFMA_PARTIALS);
+    int rc;
+    if (mode == MODE_DECODE) {
+        rc = A.p.NT == 1 ? launch_apply<1, MODE_DECODE>(A, grid, s)
+           : A.p.NT == 2 ? launch_apply<2, MODE_DECODE>(A, grid, s)
+                         : launch_apply<4, MODE_DECODE>(A, grid, s);
+    } else {
+        rc = A.p.NT == 1 ? launch_apply<1, MODE_EVAL>(A, grid, s)
+           : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s)
+                         : launch_apply<4, MODE_EVAL>(A, grid, s);
+        if (rc) return rc;
+        k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, grid, sse);
+        LBDRN_LAUNCH_CHECK();
+    }
+    return rc;
+}
+
+int mfma_decode(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* msb, const float* params,
+                uint16_t* out, float* y_out, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    return run_apply(g, net, MODE_DECODE, nullptr, msb, params, out, y_out, nullptr, ws, ws_bytes, s);
+}
+
+int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
+                  const uint16_t* msb, const float* params, double* sse, void* ws, size_t ws_bytes,
+                  hipStream_t s)
+{
+    return run_apply(g, net, MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes, s);
+}
+
+}  // namespace lbdrn

@@ -1,0 +1,48 @@
+"""Build liblbdrn_hip.so for gfx950 with hipcc (in-tree, next to the Python host code).
+
+    python lbdrn-msic_amd/csrc/build.py [--force]
+
+-ffp-contract=off: the canonical arithmetic (lbdrn_math.hpp) spells out every fma; the compiler
+must not invent more.  -fhip-fp32-correctly-rounded-divide-sqrt: IEEE division for the
+normalisation p = msb/max and the sigmoid (the reference divides in numpy / torch float32).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRCS = ["cabi.hip", "generic.hip", "apply_mfma.hip", "train_mfma.hip"]
+HDRS = ["common.hpp", "lbdrn_math.hpp", "../../include/lbdrn_hip.h"]
+OUT = os.path.join(os.path.dirname(HERE), "liblbdrn_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SRCS + HDRS + ["build.py"])
+
+
+def build(force=False, extra=()):
+    if not force and not stale():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SRCS:
+        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc, "-c"] + [f for f in FLAGS if f != "-shared"] + list(extra) + \
+              ["-o", obj, os.path.join(HERE, src)]
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,218 @@
+// extern "C" entry points of liblbdrn_hip.so (declared in include/lbdrn_hip.h).
+// Argument checking, path selection (fused MFMA kernels vs generic kernels) and nothing else.
+#include <string>
+
+#include "common.hpp"
+
+namespace lbdrn {
+const char* last_error();
+bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net);
+size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
+int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
+                     const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
+                     float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
+                     size_t ws_bytes, hipStream_t s);
+}  // namespace lbdrn
+
+using namespace lbdrn;
+
+static int device_ok()
+{
+    static thread_local int cached = 1;  // 1 = unknown, 0 = ok, <0 = error
+    if (cached != 1) return cached;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        set_error("no HIP device available (%s); liblbdrn_hip has no CPU path",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return cached = LBDRN_E_DEVICE;
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        set_error("cannot query the current HIP device");
+        return cached = LBDRN_E_DEVICE;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error("device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        return cached = LBDRN_E_DEVICE;
+    }
+    return cached = 0;
+}
+
+#define NEED_DEVICE()                  \
+    do {                               \
+        if (int rc_ = device_ok()) return rc_; \
+    } while (0)
+
+static int net_matches(const lbdrn_geom* g, const lbdrn_net* net)
+{
+    LBDRN_REQUIRE(net->F == feature_dim(*g), "net.F=%d but the geometry yields %d features", net->F,
+                  feature_dim(*g));
+    LBDRN_REQUIRE(net->C == g->C, "net.C=%d but the image has %d bands", net->C, g->C);
+    LBDRN_REQUIRE(g->msb_max >= 0 && g->msb_max <= 65535, "msb_max=%d out of range", g->msb_max);
+    return 0;
+}
+
+extern "C" {
+
+const char* lbdrn_last_error(void) { return last_error(); }
+int lbdrn_abi_version(void) { return LBDRN_ABI_VERSION; }
+int lbdrn_device_check(void) { return device_ok(); }
+
+int64_t lbdrn_param_count(const lbdrn_net* net)
+{
+    if (check_net(net)) return LBDRN_E_ARG;
+    return param_count(*net);
+}
+
+int32_t lbdrn_feature_dim(const lbdrn_geom* g)
+{
+    if (!g) return LBDRN_E_ARG;
+    return feature_dim(*g);
+}
+
+int lbdrn_split_bits(const uint16_t* img, int32_t C, int32_t H, int32_t W, int32_t K, uint16_t* msb,
+                     int32_t* msb_max, void* stream)
+{
+    LBDRN_REQUIRE(img && msb_max, "img and msb_max must not be null");
+    LBDRN_REQUIRE(C >= 1 && H >= 1 && W >= 1 && K >= 1 && K <= 15, "bad arguments C=%d H=%d W=%d K=%d", C, H, W, K);
+    NEED_DEVICE();
+    return generic_split_bits(img, C, H, W, K, msb, msb_max, (hipStream_t)stream);
+}
+
+int lbdrn_labels(const uint16_t* img, int32_t C, int32_t H, int32_t W, int32_t K, const int64_t* idx,
+                 int64_t n, float* labels, void* stream)
+{
+    LBDRN_REQUIRE(img && labels, "img and labels must not be null");
+    LBDRN_REQUIRE(C >= 1 && H >= 1 && W >= 1 && K >= 1 && K <= 15 && n >= 0, "bad arguments");
+    LBDRN_REQUIRE(idx || n <= (int64_t)H * W, "n exceeds the pixel count");
+    NEED_DEVICE();
+    return generic_labels(img, C, H, W, K, idx, n, labels, (hipStream_t)stream);
+}
+
+int lbdrn_features(const lbdrn_geom* g, const uint16_t* msb, const int64_t* idx, int64_t n,
+                   float* features, void* stream)
+{
+    if (int rc = check_geom(g)) return rc;
+    LBDRN_REQUIRE(msb && features && n >= 0, "msb/features null or n negative");
+    LBDRN_REQUIRE(idx || n <= (int64_t)g->H * g->W, "n exceeds the pixel count");
+    NEED_DEVICE();
+    return generic_features(*g, msb, idx, n, 0, features, (hipStream_t)stream);
+}
+
+size_t lbdrn_forward_workspace(const lbdrn_net* net, int64_t B)
+{
+    if (check_net(net) || B < 0) return 0;
+    return generic_forward_workspace(*net, B);
+}
+
+int lbdrn_forward(const lbdrn_net* net, const float* params, const float* x, int64_t B, float* y,
+                  void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (int rc = check_net(net)) return rc;
+    LBDRN_REQUIRE(params && x && y && B >= 0, "null pointer or negative batch");
+    NEED_DEVICE();
+    return generic_forward(*net, params, x, B, y, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t lbdrn_apply_workspace(const lbdrn_geom* g, const lbdrn_net* net)
+{
+    if (check_geom(g) || check_net(net)) return 0;
+    size_t a = generic_apply_workspace(*g, *net);
+    size_t b = mfma_apply_supported(*g, *net) ? mfma_apply_workspace(*g, *net) : 0;
+    return a > b ? a : b;
+}
+
+static int pick_apply(const lbdrn_geom* g, const lbdrn_net* net, int32_t path, bool* use_mfma)
+{
+    const bool ok = mfma_apply_supported(*g, *net);
+    if (path == LBDRN_PATH_MFMA && !ok) {
+        set_error("fused MFMA apply kernel does not support bc=%d nl=%d C=%d D=%d", net->bc, net->nl,
+                  net->C, g->D);
+        return LBDRN_E_UNSUPPORTED;
+    }
+    LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
+    *use_mfma = ok && path != LBDRN_PATH_GENERIC;
+    return 0;
+}
+
+int lbdrn_decode_fused(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t* msb,
+                       const float* params, uint16_t* out, float* y_out, void* workspace,
+                       size_t workspace_bytes, int32_t path, void* stream)
+{
+    if (int rc = check_geom(g)) return rc;
+    if (int rc = check_net(net)) return rc;
+    if (int rc = net_matches(g, net)) return rc;
+    LBDRN_REQUIRE(msb && params && out, "msb, params and out must not be null");
+    NEED_DEVICE();
+    bool use_mfma = false;
+    if (int rc = pick_apply(g, net, path, &use_mfma)) return rc;
+    if (use_mfma)
+        return mfma_decode(*g, *net, msb, params, out, y_out, workspace, workspace_bytes, (hipStream_t)stream);
+    return generic_decode(*g, *net, msb, params, out, y_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int lbdrn_eval_sse(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t* img, const uint16_t* msb,
+                   const float* params, double* sse, void* workspace, size_t workspace_bytes,
+                   int32_t path, void* stream)
+{
+    if (int rc = check_geom(g)) return rc;
+    if (int rc = check_net(net)) return rc;
+    if (int rc = net_matches(g, net)) return rc;
+    LBDRN_REQUIRE(img && msb && params && sse, "img, msb, params and sse must not be null");
+    NEED_DEVICE();
+    bool use_mfma = false;
+    if (int rc = pick_apply(g, net, path, &use_mfma)) return rc;
+    if (use_mfma)
+        return mfma_eval_sse(*g, *net, img, msb, params, sse, workspace, workspace_bytes, (hipStream_t)stream);
+    return generic_eval_sse(*g, *net, img, msb, params, sse, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t lbdrn_train_workspace(const lbdrn_geom* g, const lbdrn_net* net, int32_t batch_size)
+{
+    if (check_geom(g) || check_net(net) || batch_size < 1) return 0;
+    size_t a = generic_train_workspace(*net, batch_size);
+    size_t b = mfma_train_supported(*g, *net) ? mfma_train_workspace(*g, *net, batch_size) : 0;
+    return a > b ? a : b;
+}
+
+int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t* img,
+                      const uint16_t* msb, const int64_t* perm, int64_t n, int32_t batch_size,
+                      float* params, float* exp_avg, float* exp_avg_sq, int64_t adam_step0, double lr,
+                      float* losses, void* workspace, size_t workspace_bytes, int32_t path,
+                      void* stream)
+{
+    if (int rc = check_geom(g)) return rc;
+    if (int rc = check_net(net)) return rc;
+    if (int rc = net_matches(g, net)) return rc;
+    LBDRN_REQUIRE(img && msb && perm && params && exp_avg && exp_avg_sq, "null pointer");
+    LBDRN_REQUIRE(n >= 0 && batch_size >= 1 && adam_step0 >= 0, "bad n/batch_size/adam_step0");
+    NEED_DEVICE();
+    const bool ok = mfma_train_supported(*g, *net);
+    if (path == LBDRN_PATH_MFMA && !ok) {
+        set_error("fused MFMA train kernel does not support this shape");
+        return LBDRN_E_UNSUPPORTED;
+    }
+    LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
+    if (ok && path != LBDRN_PATH_GENERIC)
+        return mfma_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
+                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
+    return generic_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
+                               adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int lbdrn_train_step(const lbdrn_net* net, const float* x, const float* t, int32_t B, float* params,
+                     float* exp_avg, float* exp_avg_sq, int64_t adam_step, double lr,
+                     int32_t apply_adam, float* loss, float* grads, void* workspace,
+                     size_t workspace_bytes, void* stream)
+{
+    if (int rc = check_net(net)) return rc;
+    LBDRN_REQUIRE(x && t && params, "x, t and params must not be null");
+    LBDRN_REQUIRE(!apply_adam || (exp_avg && exp_avg_sq && adam_step >= 1), "Adam state missing or adam_step < 1");
+    NEED_DEVICE();
+    return generic_train_step(*net, x, t, B, params, exp_avg, exp_avg_sq, adam_step, lr, apply_adam,
+                              loss, grads, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+"""LBDRN-MSIC decoder, MI355X build: same command line, log records and reconstruction as the
+reference's decode.py (ref decode.py:151-224); feature rebuild, network forward, rounding and
+integer reconstruction run as one fused HIP kernel (lbdrn_hip.codec.apply_image)."""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+import logger
+from lbdrn_hip import codec, container, raster_io
+from lbdrn_hip.features import FeatCfg
+from LBDRNdataset import tile_windows, write_tiff_with_gdal
+
+DEVICE = "cuda:0"
+K = D = bc = nl = None  # set from the header; test() reads them like the reference's does
+
+
+def read_image_header(bitstream):
+    return container.unpack_header(bitstream)
+
+
+def test(bitstream, dirname, filename, nn_bytes, base_bytes, write=True):
+    """Decode one image or tile from the front of `bitstream`; returns the remaining bytes
+    (ref decode.py:56-141)."""
+    nn_payload, bitstream = bitstream[:nn_bytes], bitstream[nn_bytes:]
+    base_payload, bitstream = bitstream[:base_bytes], bitstream[base_bytes:]
+    base = container.decode_base(base_payload)
+    params = container.decode_weights(nn_payload)
+    image = codec.apply_image(base, params, K, D, bc, nl, cfg=FeatCfg.from_constants(), device=DEVICE)
+    recon_path = f"{dirname}/{filename}_recon.tif"
+    test.last_image = image
+    if write:
+        write_tiff_with_gdal(recon_path, image)
+        logger.log.info(f"Recon: {recon_path}")
+    return bitstream
+
+
+def main(argv=None):
+    global K, D, bc, nl
+    p = argparse.ArgumentParser(description="LBDRN-RSIC")
+    p.add_argument("--seed", type=int, default=19920517)
+    p.add_argument("-i", "--bin_path", type=str, help="binstream path")
+    p.add_argument("-org", "--org_path", type=str, default=None, help="org path")
+    args = p.parse_args(argv)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    random.seed(args.seed)
+    dirname, basename = os.path.split(args.bin_path)
+    dirname = dirname or "."
+    filename = os.path.splitext(basename)[0]
+    if os.path.exists(f"{dirname}/decode.txt"):
+        with open(f"{dirname}/decode.txt") as f:
+            if "bpsp" in f.read():
+                print("Bitstream already decoded!")
+                return 0
+    logger.create_logger(dirname, "decode.txt")
+    logger.log.info(f"Binstream: {args.bin_path}")
+    start_time = time.time()
+    with open(args.bin_path, "rb") as fin:
+        bitstream = fin.read()
+    n_hdr, split_ratio, width, height, K, bc, nl, D, nn_list, base_list = read_image_header(bitstream)
+    bitstream = bitstream[n_hdr:]
+    recon_path = f"{dirname}/{basename[:-4]}_recon.tif"
+    if split_ratio > 1:
+        merged = None
+        for t, (i, j, x0, y0, w, h) in enumerate(tile_windows(width, height, split_ratio)):
+            bitstream = test(bitstream, dirname, f"tile_{i}_{j}", nn_list[t], base_list[t], write=False)
+            tile = test.last_image
+            if merged is None:
+                merged = np.zeros((tile.shape[0], height, width), tile.dtype)
+            merged[:, y0:y0 + h, x0:x0 + w] = tile
+        write_tiff_with_gdal(recon_path, merged)
+    else:
+        bitstream = test(bitstream, dirname, filename, nn_list[0], base_list[0])
+    logger.log.info(f"Time elapsed: {time.time() - start_time}")
+    if args.org_path is not None:
+        org_img = raster_io.read_raster(args.org_path)
+        rec_img = raster_io.read_raster(recon_path)
+        nbytes = os.path.getsize(args.bin_path)
+        mse_value = np.mean((org_img.astype(np.float32) - rec_img.astype(np.float32)) ** 2)
+        logger.log.info(f"MSE: {mse_value}")
+        psnr = 10 * np.log10(10000 ** 2 / mse_value)    # peak fixed at 10000 (ref decode.py:218)
+        logger.log.info(f"PSNR: {psnr}")
+        logger.log.info(f"Total size: {nbytes} bytes, bpsp={nbytes * 8 / np.prod(org_img.shape)}")
+        os.remove(recon_path)                             # ref decode.py:223-224
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

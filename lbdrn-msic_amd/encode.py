@@ -1,0 +1,128 @@
+"""LBDRN-MSIC encoder, MI355X build: same command line, output directory naming, .bin container
+and log records as the reference's encode.py (ref encode.py:167-289); the per-image fit runs as
+fused HIP kernels (lbdrn_hip.codec.fit_image) instead of DataLoader + ignite + autograd.
+
+Bitstream: header | for each tile (row-major): network payload | MSB payload   (ref encode.py:29-36)
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+import logger
+from lbdrn_hip import codec, container, raster_io
+from lbdrn_hip.features import FeatCfg
+from LBDRNdataset import tile_windows
+
+DEVICE = "cuda:0"
+
+
+def write_image_header(header_path, split_ratio, width, height, K, bc, nl, D, nn_bytes_list,
+                       base_bytes_list):
+    data = container.pack_header(split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_bytes_list)
+    with open(header_path, "wb") as f:
+        f.write(data)
+    if os.path.getsize(header_path) != data[0]:
+        raise ValueError(f"Invalid number of bytes in header! expected {data[0]}, "
+                         f"got {os.path.getsize(header_path)}")
+
+
+def train(args, img=None):
+    """Fit one image or tile and return (nn_payload, base_payload); logs what the reference logs
+    (ref encode.py:67-157)."""
+    if img is None:
+        img = raster_io.read_raster(args.path)
+    filename = os.path.splitext(os.path.basename(args.path))[0]
+    res = codec.fit_image(img, args.K, args.D, args.base_channel, args.num_layers, args.lr,
+                          args.batch_size, args.epochs, args.val_duration,
+                          cfg=FeatCfg.from_constants(), device=DEVICE)
+    logger.log.info("total_params: {}".format(res.params.size))
+    for epoch, mse, improved in res.epoch_mse:
+        if improved:
+            logger.log.info("Save current best val model (MSE: {:.5f}) @epoch {}".format(mse, epoch))
+        else:
+            logger.log.info("Model is not updated (MSE: {:.5f}) @epoch: {}".format(mse, epoch))
+    logger.log.info("best epoch: {}".format(res.best_epoch))
+    nn_payload = container.encode_weights(res.params, args.precision)      # ref encode.py:129
+    logger.log.info(f"nn: {len(nn_payload)} bytes, bpsp={len(nn_payload) * 8 / res.n_subpixels}")
+    base_payload = container.encode_base(res.msb)                           # ref encode.py:137
+    logger.log.info(f"MSB: {len(base_payload)} bytes: bpsp={len(base_payload) * 8 / res.n_subpixels}")
+    logger.log.info(f"{filename}: fit {res.seconds['fit']:.3f}s on {DEVICE}")
+    return nn_payload, base_payload
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="LBDRN-MSIC")
+    p.add_argument("--seed", type=int, default=19920517)
+    p.add_argument("-rn", "--randomness", action="store_true", help="Allow randomness during training?")
+    p.add_argument("-i", "--path", type=str, help="path of input tif or img file")
+    p.add_argument("-o", "--output_dir", default="outputs", type=str, help="output dir")
+    p.add_argument("-sr", "--split_ratio", type=int, default=1, help="tile size (default: 1)")
+    p.add_argument("-K", "--K", type=int, default=5, help=" (default: 5)")
+    p.add_argument("-bc", "--base_channel", type=int, default=64, help="base channel (default: 64)")
+    p.add_argument("-nl", "--num_layers", type=int, default=2, help="Number of layers (default: 2)")
+    p.add_argument("-D", "--D", type=int, default=2, help="#neighbors (2D+1)^2")
+    p.add_argument("-prec", "--precision", type=int, default=16, help=" (default: 16)")
+    p.add_argument("-lr", "--lr", type=float, default=1e-3, help="learning rate (default: 1e-3)")
+    p.add_argument("-bs", "--batch_size", type=int, default=8192, help="batch size (default: 8192)")
+    p.add_argument("-e", "--epochs", type=int, default=10, help="number of epochs to train (default: 10)")
+    p.add_argument("-vd", "--val_duration", type=int, default=1,
+                   help="number of epoch duration for val (default: 1)")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if not args.randomness:
+        torch.manual_seed(args.seed)
+        np.random.seed(args.seed)
+        random.seed(args.seed)
+    org_path = args.path
+    filename = os.path.splitext(os.path.basename(org_path))[0]
+    args.output_dir = "{}/{}_r{}_K{}_bc{}_nl{}_D{}_prec{}_lr{}_bs{}_e{}".format(
+        args.output_dir, filename, args.split_ratio, args.K, args.base_channel, args.num_layers,
+        args.D, args.precision, args.lr, args.batch_size, args.epochs)
+    os.makedirs(args.output_dir, exist_ok=True)
+    bitstream_path = f"{args.output_dir}/{filename}.bin"
+    log_path = f"{args.output_dir}/encode.txt"
+    if os.path.exists(log_path) and os.path.exists(bitstream_path):
+        with open(log_path) as f:
+            if "Time elapsed" in f.read():
+                print("Bitstream already created!")
+                return 0
+    logger.create_logger(args.output_dir, "encode.txt")
+    start_time = time.time()
+    img = raster_io.read_raster(org_path)
+    img = img.reshape((-1,) + img.shape[-2:])
+    height, width = img.shape[-2:]
+    nn_payloads, base_payloads = [], []
+    if args.split_ratio > 1:
+        for i, j, x0, y0, w, h in tile_windows(width, height, args.split_ratio):
+            args.path = f"{args.output_dir}/tile_{i}_{j}.tif"
+            logger.log.info(args)
+            nn, base = train(args, np.ascontiguousarray(img[:, y0:y0 + h, x0:x0 + w]))
+            nn_payloads.append(nn)
+            base_payloads.append(base)
+    else:
+        logger.log.info(args)
+        nn, base = train(args, img)
+        nn_payloads.append(nn)
+        base_payloads.append(base)
+    header = container.pack_header(args.split_ratio, width, height, args.K, args.base_channel,
+                                   args.num_layers, args.D, [len(b) for b in nn_payloads],
+                                   [len(b) for b in base_payloads])
+    with open(bitstream_path, "wb") as f:
+        f.write(header)
+        for nn, base in zip(nn_payloads, base_payloads):
+            f.write(nn)
+            f.write(base)
+    logger.log.info(f"Time elapsed: {time.time() - start_time}")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,0 +1,177 @@
+"""Per-image fit (encode side) and apply (decode side) loops on the GPU.
+
+fit_image() stands where the reference's encode.train() stands (ref encode.py:67-157) and
+apply_image() where decode.test()'s numeric core stands (ref decode.py:73-134); file handling,
+payload coding and logging stay in encode.py / decode.py.
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import ops
+from .features import FeatCfg
+from .model import LBDRNModel
+from .sampler import PermutationStream
+
+
+def lr_schedule(lr, epochs):
+    """Learning rate in force during each epoch: StepLR(step_size=max(1,int(epochs/3)), gamma=0.1)
+    stepped at every epoch end (ref encode.py:85,98); chained float64 products like torch's."""
+    step = max(1, int(epochs / 3))
+    out, cur = [], float(lr)
+    for e in range(1, epochs + 1):
+        out.append(cur)
+        if e % step == 0:
+            cur *= 0.1
+    return out
+
+
+class FitResult:
+    def __init__(self):
+        self.params = None          # best parameters, float32 numpy, state_dict order
+        self.best_epoch = -1
+        self.best_mse = None
+        self.epoch_mse = []         # (epoch, mse, improved)
+        self.losses = None          # per-step minibatch losses [epochs][steps] (device tensor)
+        self.msb = None             # MSB plane, numpy uint8/uint16 [C,H,W]
+        self.msb_max = None
+        self.n_feature = None
+        self.channels = None
+        self.n_subpixels = None
+        self.seconds = {}
+
+
+class DeviceFit:
+    """Result of fit_device(): everything still in HBM; host() syncs once."""
+
+    def __init__(self):
+        self.best_params = None   # device float32 [NP]
+        self.msb = None           # device int16-storage uint16 [C,H,W]
+        self.msb_max = None
+        self.geom = None
+        self.net = None
+        self.mse_log = None       # device [epochs,2]: mse, improved flag
+        self.evaluated = []
+        self.losses = None
+        self.epochs = 0
+
+
+def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1,
+               cfg=None, path=ops.PATH_AUTO, keep_losses=False, perm_workers=4):
+    """Fit one image that already sits in HBM (img_d: [C,H,W] uint16 bits in int16 storage).
+
+    The caller has seeded torch (ref encode.py:200-205); the global CPU generator is consumed
+    exactly as the reference's train() consumes it: model construction, then one DataLoader
+    iterator per train / eval pass (lbdrn_hip.sampler).  No host synchronisation happens inside
+    except the scalar read of MSB.max() that sizes the normalisation (ref LBDRNdataset.py:120)."""
+    cfg = cfg or FeatCfg.from_constants()
+    out = DeviceFit()
+    dev = img_d.device
+    C, H, W = img_d.shape
+    N = H * W
+    msb_d, msb_max = ops.split_bits(img_d, K)            # a1
+    geom = ops.FeatureGeometry(C, H, W, K, D, msb_max, cfg, dev)
+    # model on the CPU first, like the reference (encode.py:71-77): consumes the global generator
+    model = LBDRNModel(dim_in=geom.F, dim_hidden=base_channel, dim_out=C, num_layers=num_layers)
+    net = model.hip_net()
+    params = model.flat_parameters().to(dev).contiguous()
+    exp_avg = torch.zeros_like(params)
+    exp_avg_sq = torch.zeros_like(params)
+    stream = PermutationStream(N, epochs, val_duration, workers=perm_workers)
+    lrs = lr_schedule(lr, epochs)
+    steps_per_epoch = (N + batch_size - 1) // batch_size
+    losses = torch.zeros((epochs, steps_per_epoch), dtype=torch.float32, device=dev) if keep_losses else None
+    train_ws = ops.TrainWorkspace(geom, net, batch_size, dev)
+    apply_ws = ops.ApplyWorkspace(geom, net, dev)
+    best_params = params.clone()
+    best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)   # encode.py:91
+    mse_log = torch.zeros((epochs, 2), dtype=torch.float32, device=dev)
+    adam_steps = 0
+    for e in range(1, epochs + 1):
+        perm = stream.get(e).to(dev, non_blocking=True)                  # a4
+        ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
+                        adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
+        adam_steps += steps_per_epoch
+        if epochs == 1:                                                   # encode.py:100-103
+            best_params.copy_(params)
+        elif e % min(val_duration, epochs) == 0:                          # encode.py:104-117
+            sse = ops.eval_sse(geom, net, img_d, msb_d, params, path, apply_ws)   # a9
+            mse = (sse / float(N * C)).float()
+            improved = mse < best_mse
+            best_params = torch.where(improved, params, best_params)
+            best_mse = torch.where(improved, mse, best_mse)
+            mse_log[e - 1, 0] = mse[0]
+            mse_log[e - 1, 1] = improved[0].float()
+            out.evaluated.append(e)
+    stream.close()
+    out.best_params, out.msb, out.msb_max, out.geom, out.net = best_params, msb_d, msb_max, geom, net
+    out.mse_log, out.losses, out.epochs = mse_log, losses, epochs
+    return out
+
+
+def truncate_device(params, precision):
+    """Device-side twin of container.truncate_precision (what the decoder sees after the weight
+    payload round trip)."""
+    if precision in (0, 32):
+        return params.clone()
+    mask = -(1 << (32 - precision))
+    return (params.view(torch.int32) & mask).view(torch.float32)
+
+
+def apply_device(geom, net, msb_d, params_d, path=ops.PATH_AUTO, ws=None, want_y=False):
+    """Reconstruct from HBM-resident MSB plane + weights (ref decode.py:122-134)."""
+    return ops.decode_fused(geom, net, msb_d, params_d, want_y=want_y, path=path, ws=ws)
+
+
+def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
+              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, perm_workers=4):
+    """Host-array front end of fit_device(): img numpy uint16 [C,H,W] or [H,W] -> FitResult."""
+    res = FitResult()
+    t0 = time.time()
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    if img.ndim == 2:
+        img = img[None]
+    C, H, W = img.shape
+    img_d = ops.to_device_u16(img, torch.device(device))
+    res.seconds["upload"] = time.time() - t0
+    t1 = time.time()
+    fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
+                     path, keep_losses, perm_workers)
+    mse_host = fit.mse_log.cpu().numpy()                                  # the one sync of the fit
+    res.seconds["fit"] = time.time() - t1
+    if epochs == 1:
+        res.best_epoch = 1
+    for e in fit.evaluated:
+        res.epoch_mse.append((e, float(mse_host[e - 1, 0]), bool(mse_host[e - 1, 1] > 0)))
+        if mse_host[e - 1, 1] > 0:
+            res.best_epoch, res.best_mse = e, float(mse_host[e - 1, 0])
+    res.params = fit.best_params.cpu().numpy()
+    msb = ops.from_device_u16(fit.msb)
+    res.msb = msb.astype(np.uint16) if fit.msb_max > 255 else msb.astype(np.uint8)   # LBDRNdataset.py:100
+    res.msb_max = fit.msb_max
+    res.n_feature, res.channels, res.n_subpixels = fit.geom.F, C, H * W * C
+    res.losses = fit.losses
+    return res
+
+
+def apply_image(base, params, K, D, base_channel, num_layers, cfg=None, device="cuda:0",
+                path=ops.PATH_AUTO, want_y=False):
+    """Reconstruct one image (or tile) from its MSB plane and fitted weights (ref decode.py:73-134).
+    base: numpy [C,H,W] (uint8 or uint16); params: float32 vector in state_dict order."""
+    cfg = cfg or FeatCfg.from_constants()
+    base = np.ascontiguousarray(base).astype(np.uint16)                   # decode.py:74
+    if base.ndim == 2:
+        base = base[None]
+    C, H, W = base.shape
+    dev = torch.device(device)
+    msb_d = ops.to_device_u16(base, dev)
+    geom = ops.FeatureGeometry(C, H, W, K, D, int(base.max()), cfg, dev)  # divisor base.max(): decode.py:93
+    net = ops.make_net(geom.F, base_channel, C, num_layers)
+    p = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float32)).to(dev)
+    if p.numel() != ops.param_count(net):
+        raise ValueError(f"weight payload has {p.numel()} values, the network needs {ops.param_count(net)}")
+    out = ops.decode_fused(geom, net, msb_d, p, want_y=want_y, path=path)
+    if want_y:
+        return ops.from_device_u16(out[0]), out[1].cpu().numpy()
+    return ops.from_device_u16(out)

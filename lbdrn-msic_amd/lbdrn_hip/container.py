@@ -1,0 +1,165 @@
+""".bin container of the codec: header (a12) + per tile the network payload and the MSB payload.
+
+Header layout (ref encode.py:37-64, decode.py:25-53), big-endian:
+  hdr_len:u8  split_ratio:u8  width:u16  height:u16  (K<<4)|D:u8  (log2(bc)<<4)|nl:u8
+  nn_bytes:u24 x sr^2   base_bytes:u32 x sr^2
+The two payload codecs of the reference are third-party programs that are absent from this image
+(fpzip 1.2.4 for the weights, GDAL/OpenJPEG lossless JP2 for the MSB plane).  When they are
+importable they are used, which gives bitstreams the reference can read; otherwise private,
+clearly tagged payloads are written (see the two *_PRIVATE_MAGIC tags): the container layout is
+the reference's, the payload bytes are not.  DESIGN.md "Container" states what is and is not
+interchangeable.
+"""
+import lzma
+import struct
+import zlib
+
+import numpy as np
+
+NN_PRIVATE_MAGIC = b"LBW1"
+BASE_PRIVATE_MAGIC = b"LBB1"
+
+
+# ---------------------------------------------------------------- header
+
+def pack_header(split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_bytes_list):
+    tiles = split_ratio * split_ratio
+    if len(nn_bytes_list) != tiles or len(base_bytes_list) != tiles:
+        raise ValueError("one nn and one base size per tile expected")
+    log2bc = int(bc).bit_length() - 1
+    if 1 << log2bc != bc:
+        raise ValueError(f"base_channel must be a power of two for the header nibble, got {bc}")
+    for name, v, hi in (("K", K, 15), ("D", D, 15), ("nl", nl, 15), ("log2(bc)", log2bc, 15),
+                        ("width", width, 65535), ("height", height, 65535), ("split_ratio", split_ratio, 255)):
+        if not 0 <= v <= hi:
+            raise OverflowError(f"{name}={v} does not fit its header field (max {hi})")
+    n = 8 + 7 * tiles
+    if n > 255:
+        raise OverflowError(f"header of {n} bytes does not fit its one-byte length field")
+    out = struct.pack(">BBHHBB", n, split_ratio, width, height, (K << 4) | D, (log2bc << 4) | nl)
+    for b in nn_bytes_list:
+        if not 0 <= b < 1 << 24:
+            raise OverflowError(f"nn payload of {b} bytes does not fit 3 bytes")
+        out += int(b).to_bytes(3, "big")
+    for b in base_bytes_list:
+        if not 0 <= b < 1 << 32:
+            raise OverflowError(f"base payload of {b} bytes does not fit 4 bytes")
+        out += struct.pack(">I", b)
+    assert len(out) == n
+    return out
+
+
+def unpack_header(buf):
+    """-> (n_bytes_header, split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_bytes_list)"""
+    n, sr, width, height, kd, bcnl = struct.unpack_from(">BBHHBB", buf, 0)
+    tiles = sr * sr
+    pos = 8
+    nn = [int.from_bytes(buf[pos + 3 * i: pos + 3 * i + 3], "big") for i in range(tiles)]
+    pos += 3 * tiles
+    base = [struct.unpack_from(">I", buf, pos + 4 * i)[0] for i in range(tiles)]
+    return n, sr, width, height, kd >> 4, 1 << (bcnl >> 4), bcnl & 15, kd & 15, nn, base
+
+
+# ---------------------------------------------------------------- weights payload (a10)
+
+def flatten_state(state_dict):
+    """state_dict tensors in key order, C order, one float32 vector (ref encode.py:123-128)."""
+    return np.concatenate([v.detach().cpu().numpy().astype(np.float32).reshape(-1)
+                           for v in state_dict.values()])
+
+
+def unflatten_state(flat, like_state_dict):
+    """Inverse walk (ref decode.py:114-120)."""
+    import torch
+    out, k = {}, 0
+    for name, ref in like_state_dict.items():
+        n = ref.numel()
+        out[name] = torch.from_numpy(np.ascontiguousarray(flat[k:k + n]).reshape(tuple(ref.shape)).copy())
+        k += n
+    if k != flat.size:
+        raise ValueError(f"parameter vector has {flat.size} values, the model takes {k}")
+    return out
+
+
+def truncate_precision(flat, precision):
+    """This package's model of fpzip's lossy mode: keep the `precision` most significant bits of
+    each float32 (sign, exponent, leading mantissa bits), clear the rest.  NOT verified against
+    fpzip itself (absent here); precision 0 or 32 = lossless."""
+    if precision in (0, 32):
+        return flat.astype(np.float32).copy()
+    if not 2 <= precision < 32:
+        raise ValueError(f"precision {precision} outside [2,32]")
+    mask = np.uint32((0xFFFFFFFF << (32 - precision)) & 0xFFFFFFFF)
+    return (flat.astype(np.float32).view(np.uint32) & mask).view(np.float32)
+
+
+def encode_weights(flat, precision):
+    flat = np.ascontiguousarray(flat, dtype=np.float32)
+    try:
+        import fpzip  # reference-compatible stream when the codec exists (ref encode.py:129)
+        return fpzip.compress(flat, precision=precision, order="C")
+    except ImportError:
+        pass
+    q = truncate_precision(flat, precision).view(np.uint32)
+    nbytes = 4 if precision in (0, 32) else (precision + 7) // 8
+    planes = [((q >> (24 - 8 * i)) & 0xFF).astype(np.uint8).tobytes() for i in range(nbytes)]
+    body = zlib.compress(b"".join(planes), 9)
+    return NN_PRIVATE_MAGIC + struct.pack(">BI", precision, flat.size) + body
+
+
+def decode_weights(buf):
+    if buf[:4] != NN_PRIVATE_MAGIC:
+        import fpzip  # a stream written by the reference (ref decode.py:113)
+        return np.asarray(fpzip.decompress(bytes(buf), order="C")[0][0][0], dtype=np.float32)
+    precision, count = struct.unpack_from(">BI", buf, 4)
+    nbytes = 4 if precision in (0, 32) else (precision + 7) // 8
+    raw = np.frombuffer(zlib.decompress(bytes(buf[9:])), np.uint8).reshape(nbytes, count)
+    q = np.zeros(count, np.uint32)
+    for i in range(nbytes):
+        q |= raw[i].astype(np.uint32) << np.uint32(24 - 8 * i)
+    return q.view(np.float32)
+
+
+# ---------------------------------------------------------------- MSB-plane payload
+
+def _have_gdal_jp2():
+    try:
+        from osgeo import gdal
+        return gdal.GetDriverByName("JP2OpenJPEG") is not None
+    except Exception:
+        return False
+
+
+def encode_base(msb):
+    """Lossless MSB plane [C,H,W] (uint8 when max <= 255 else uint16, ref LBDRNdataset.py:100).
+
+    Private payload: the plane predictor x[i,j] - x[i-1,j] - x[i,j-1] + x[i-1,j-1] (mod 2^16),
+    zig-zag folded, high and low bytes split, LZMA."""
+    msb = np.ascontiguousarray(msb)
+    C, H, W = msb.shape
+    code = 1 if msb.dtype == np.uint8 else 2
+    x = msb.astype(np.uint16)
+    d = x.copy()
+    d[:, 1:, :] -= x[:, :-1, :]
+    e = d.copy()
+    e[:, :, 1:] -= d[:, :, :-1]
+    s = e.view(np.int16).astype(np.int32)
+    z = ((s << 1) ^ (s >> 31)).astype(np.uint16)  # zig-zag
+    body = lzma.compress((z >> 8).astype(np.uint8).tobytes() + (z & 0xFF).astype(np.uint8).tobytes(),
+                         preset=6)
+    return BASE_PRIVATE_MAGIC + struct.pack(">BHII", code, C, H, W) + body
+
+
+def decode_base(buf):
+    if buf[:4] != BASE_PRIVATE_MAGIC:
+        raise ValueError("MSB payload is not this package's private format (a JPEG 2000 stream "
+                         "written by the reference needs GDAL/OpenJPEG, which is not installed)")
+    code, C, H, W = struct.unpack_from(">BHII", buf, 4)
+    raw = np.frombuffer(lzma.decompress(bytes(buf[15:])), np.uint8)
+    n = C * H * W
+    z = (raw[:n].astype(np.uint16) << 8) | raw[n:2 * n].astype(np.uint16)
+    s = ((z >> 1).astype(np.int32) ^ -(z & 1).astype(np.int32)).astype(np.int16)
+    e = s.view(np.uint16).reshape(C, H, W)
+    d = np.cumsum(e, axis=2, dtype=np.uint16)
+    x = np.cumsum(d, axis=1, dtype=np.uint16)
+    return x.astype(np.uint8) if code == 1 else x

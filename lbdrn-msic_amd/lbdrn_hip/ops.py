@@ -1,0 +1,195 @@
+"""torch-tensor level wrappers of the C ABI: device pointers from tensor.data_ptr(), the stream
+from torch.cuda.current_stream(); torch is plumbing (memory + streams), all arithmetic is in
+liblbdrn_hip.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Geom, Net, PATH_AUTO, check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.LbdrnError("liblbdrn_hip works on device (HBM) tensors only; there is no "
+                                  "CPU path in this package")
+
+
+def _u16(t):
+    """torch has no arithmetic on uint16; planes are carried as int16 storage with the same bits."""
+    if t.dtype == torch.uint16:
+        return t.view(torch.int16)
+    assert t.dtype == torch.int16, t.dtype
+    return t
+
+
+class FeatureGeometry:
+    """lbdrn_geom plus the device tables it points at (kept alive here)."""
+
+    def __init__(self, C, H, W, K, D, msb_max, cfg, device):
+        from .features import pos_tables
+        self.C, self.H, self.W, self.K, self.D, self.msb_max = C, H, W, K, D, int(msb_max)
+        self.cfg = cfg
+        rowtab, coltab = pos_tables(H, W, cfg)
+        self.P = rowtab.shape[1]
+        self.rowtab = torch.from_numpy(rowtab).to(device) if self.P else None
+        self.coltab = torch.from_numpy(coltab).to(device) if self.P else None
+        self.F = cfg.feature_dim(C, D)
+        self.c = Geom(C, H, W, K, D, int(msb_max), int(cfg.use_colors), int(cfg.relative), self.P,
+                      0, self.rowtab.data_ptr() if self.P else None,
+                      self.coltab.data_ptr() if self.P else None)
+
+    def with_max(self, msb_max):
+        self.msb_max = int(msb_max)
+        self.c.msb_max = int(msb_max)
+        return self
+
+
+def make_net(F, bc, C, nl):
+    return Net(F, bc, C, nl)
+
+
+def param_count(net):
+    return int(lib().lbdrn_param_count(ctypes.byref(net)))
+
+
+def split_bits(img, K):
+    """img [C,H,W] u16 (device) -> (msb [C,H,W] u16, msb_max int).  ref LBDRNdataset.py:95-101"""
+    _need_cuda(img)
+    img = _u16(img.contiguous())
+    C, H, W = img.shape
+    msb = torch.empty_like(img)
+    mx = torch.zeros(1, dtype=torch.int32, device=img.device)
+    check(lib().lbdrn_split_bits(_ptr(img), C, H, W, K, _ptr(msb), _ptr(mx), _stream()))
+    return msb, int(mx.item())
+
+
+def labels(img, K, idx=None):
+    """[n,C] f32 normalised low bits.  ref LBDRNdataset.py:96-97,131"""
+    _need_cuda(img, idx)
+    img = _u16(img.contiguous())
+    C, H, W = img.shape
+    n = H * W if idx is None else idx.numel()
+    out = torch.empty((n, C), dtype=torch.float32, device=img.device)
+    if idx is not None:
+        idx = idx.to(torch.int64).contiguous()
+    check(lib().lbdrn_labels(_ptr(img), C, H, W, K, _ptr(idx), n, _ptr(out), _stream()))
+    return out
+
+
+def features(geom, msb, idx=None):
+    """[n,F] f32 feature rows.  ref LBDRNdataset.py:104-130"""
+    _need_cuda(msb, idx)
+    msb = _u16(msb.contiguous())
+    n = geom.H * geom.W if idx is None else idx.numel()
+    out = torch.empty((n, geom.F), dtype=torch.float32, device=msb.device)
+    if idx is not None:
+        idx = idx.to(torch.int64).contiguous()
+    check(lib().lbdrn_features(ctypes.byref(geom.c), _ptr(msb), _ptr(idx), n, _ptr(out), _stream()))
+    return out
+
+
+def forward(net, params, x):
+    """LBDRNModel.forward on a feature matrix.  ref LBDRNmodel.py:79-82"""
+    _need_cuda(params, x)
+    x = x.contiguous().float()
+    params = params.contiguous().float()
+    B = x.shape[0]
+    assert x.shape[1] == net.F and params.numel() == param_count(net)
+    y = torch.empty((B, net.C), dtype=torch.float32, device=x.device)
+    nbytes = lib().lbdrn_forward_workspace(ctypes.byref(net), B)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    check(lib().lbdrn_forward(ctypes.byref(net), _ptr(params), _ptr(x), B, _ptr(y), _ptr(ws), nbytes,
+                              _stream()))
+    return y
+
+
+class ApplyWorkspace:
+    def __init__(self, geom, net, device):
+        self.nbytes = lib().lbdrn_apply_workspace(ctypes.byref(geom.c), ctypes.byref(net))
+        self.buf = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=device)
+
+
+def decode_fused(geom, net, msb, params, want_y=False, path=PATH_AUTO, ws=None):
+    """decode.py:73-134 in one call -> image [C,H,W] int16-storage u16 (and y [N,C])."""
+    _need_cuda(msb, params)
+    msb = _u16(msb.contiguous())
+    params = params.contiguous().float()
+    out = torch.empty_like(msb)
+    y = torch.empty((geom.H * geom.W, geom.C), dtype=torch.float32, device=msb.device) if want_y else None
+    ws = ws or ApplyWorkspace(geom, net, msb.device)
+    check(lib().lbdrn_decode_fused(ctypes.byref(geom.c), ctypes.byref(net), _ptr(msb), _ptr(params),
+                                   _ptr(out), _ptr(y), _ptr(ws.buf), ws.nbytes, path, _stream()))
+    return (out, y) if want_y else out
+
+
+def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None):
+    """Whole-image sum of squared error as a device float64 scalar tensor (no sync)."""
+    _need_cuda(img, msb, params)
+    img = _u16(img.contiguous())
+    msb = _u16(msb.contiguous())
+    params = params.contiguous().float()
+    sse = out if out is not None else torch.zeros(1, dtype=torch.float64, device=msb.device)
+    ws = ws or ApplyWorkspace(geom, net, msb.device)
+    check(lib().lbdrn_eval_sse(ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
+                               _ptr(params), _ptr(sse), _ptr(ws.buf), ws.nbytes, path, _stream()))
+    return sse
+
+
+class TrainWorkspace:
+    def __init__(self, geom, net, batch_size, device):
+        self.nbytes = lib().lbdrn_train_workspace(ctypes.byref(geom.c), ctypes.byref(net), batch_size)
+        self.buf = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=device)
+
+
+def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_sq, adam_step0, lr,
+                losses=None, path=PATH_AUTO, ws=None):
+    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor."""
+    _need_cuda(img, msb, perm, params, exp_avg, exp_avg_sq, losses)
+    img = _u16(img.contiguous())
+    msb = _u16(msb.contiguous())
+    assert perm.dtype == torch.int64 and perm.is_contiguous()
+    for t in (params, exp_avg, exp_avg_sq):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    ws = ws or TrainWorkspace(geom, net, batch_size, img.device)
+    check(lib().lbdrn_train_epoch(ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
+                                  _ptr(perm), perm.numel(), batch_size, _ptr(params), _ptr(exp_avg),
+                                  _ptr(exp_avg_sq), adam_step0, float(lr), _ptr(losses), _ptr(ws.buf),
+                                  ws.nbytes, path, _stream()))
+
+
+def train_step(net, x, t, params, exp_avg, exp_avg_sq, adam_step, lr, apply_adam=True):
+    """One teacher-forced update on an explicit minibatch; returns (loss tensor, grads tensor)."""
+    _need_cuda(x, t, params)
+    x = x.contiguous().float()
+    t = t.contiguous().float()
+    B = x.shape[0]
+    loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+    grads = torch.empty_like(params)
+    g = Geom(net.C, 1, 1, 1, 0, 1, 1, 1, 0, 0, None, None)
+    nbytes = lib().lbdrn_train_workspace(ctypes.byref(g), ctypes.byref(net), B)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
+    check(lib().lbdrn_train_step(ctypes.byref(net), _ptr(x), _ptr(t), B, _ptr(params), _ptr(exp_avg),
+                                 _ptr(exp_avg_sq), adam_step, float(lr), int(apply_adam), _ptr(loss),
+                                 _ptr(grads), _ptr(ws), nbytes, _stream()))
+    return loss, grads
+
+
+def to_device_u16(arr, device):
+    """numpy uint16 array -> device tensor (int16 storage, same bits)."""
+    a = np.ascontiguousarray(arr, dtype=np.uint16)
+    return torch.from_numpy(a.view(np.int16)).to(device)
+
+
+def from_device_u16(t):
+    return t.cpu().numpy().view(np.uint16)

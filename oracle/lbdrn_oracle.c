@@ -46,27 +46,19 @@ static inline float sincos_poly(float r, int quad)
     return (quad & 2) ? -v : v;
 }
 
-/* |x| > 2^16 or non-finite: reduce in float64 (two-piece pi/2) */
-static float sincos_big(float x, int shift)
-{
-    if (!(fabsf(x) < INFINITY)) return x - x;
-    double xd = (double)x;
-    double kd = rint(xd * 0x1.45f306dc9c883p-1);
-    double r = fma(-kd, 0x1.921fb54442d18p+0, xd);
-    r = fma(-kd, 0x1.1a62633145c07p-54, r);
-    double q4 = kd - 4.0 * floor(kd * 0.25);
-    return sincos_poly((float)r, (int)q4 + shift);
-}
-
-/* shift 0 -> sin(x), shift 1 -> cos(x) */
+/* shift 0 -> sin(x), shift 1 -> cos(x).  One branch-free path for every finite x: the
+ * quadrant comes from k mod 4 in float arithmetic (exact for any integer-valued float), so no
+ * float->int conversion can overflow.  Accurate to 1.5 ulp for |x| <= 2^16, to ~1e-7 absolute
+ * up to 2^23; beyond that x itself is coarser than a period. NaN/Inf propagate to NaN. */
 static inline float canon_sincos(float x, int shift)
 {
-    if (!(fabsf(x) <= 65536.0f)) return sincos_big(x, shift);
     float k = rintf(x * TWO_OVER_PI);
     float r = fmaf(-k, PIO2_A, x);
     r = fmaf(-k, PIO2_B, r);
     r = fmaf(-k, PIO2_C, r);
-    return sincos_poly(r, (int)k + shift);
+    float qf = fmaf(-4.0f, floorf(k * 0.25f), k);
+    int q = (qf >= 0.0f && qf < 4.0f) ? (int)qf : 0; /* NaN -> 0 */
+    return sincos_poly(r, q + shift);
 }
 
 /* e^(-a), 0 <= a <= 86 */

@@ -1,0 +1,259 @@
+"""Parity of the HIP path (through the C ABI) against the oracle: bit-exact for integer / byte work
+and for the canonical-arithmetic forward, 1e-5 relative for the training step."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from lbdrn_hip import ops
+from lbdrn_hip.features import FeatCfg
+
+pytestmark = pytest.mark.gpu
+
+RTOL_TRAIN = 1e-5  # north_star: encode-time float loss within 1e-5 relative
+
+
+def _cfg(flags):
+    return FeatCfg(use_coordinates=bool(flags[0]), embedding=bool(flags[1]),
+                   use_colors=bool(flags[2]), relative=bool(flags[3]))
+
+
+def _ocfg(c):
+    return O.FeatCfg(c.use_coordinates, c.embedding, c.sigma, c.n_freq, c.use_colors, c.relative)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _rand_params(rng, F, bc, C, nl, gain=1.0):
+    """SIREN-like magnitudes so that sin(30 z) wraps a few times."""
+    parts = []
+    for l in range(nl):
+        nin = F if l == 0 else bc
+        b = (1.0 / nin if l == 0 else np.sqrt(6.0 / nin) / 30.0) * gain
+        parts += [rng.uniform(-b, b, bc * nin), rng.uniform(-b, b, bc)]
+    b = np.sqrt(6.0 / bc) / 30.0 * gain
+    parts += [rng.uniform(-b, b, C * bc), rng.uniform(-b, b, C)]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def _image(rng, C, H, W, hi=10000):
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.empty((C, H, W), np.uint16)
+    for c in range(C):
+        a = np.sin(yy / (3.0 + c) + xx / (5.0 + 2 * c) + c) * 0.4 + 0.5
+        img[c] = np.clip(a * hi + rng.normal(0, hi * 0.01, (H, W)), 0, hi).astype(np.uint16)
+    return img
+
+
+# ---------------------------------------------------------------- a1-a3
+
+def test_split_labels_features_match_oracle_on_golden_cases(golden, dev):
+    G = golden["features"]
+    for name in sorted({k.split("/")[0] for k in G.files}):
+        img, K, D = G[name + "/img"], int(G[name + "/K"]), int(G[name + "/D"])
+        cfg = _cfg(G[name + "/flags"])
+        img_d = ops.to_device_u16(img, dev)
+        msb_d, mx = ops.split_bits(img_d, K)
+        msb_o, lab_o, mx_o = O.split_bits(img, K)
+        assert mx == mx_o
+        assert np.array_equal(ops.from_device_u16(msb_d), msb_o)
+        lab = ops.labels(img_d, K).cpu().numpy()
+        assert np.array_equal(_bits(lab), _bits(G[name + "/labels"])), name
+        C, H, W = img.shape
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        f = ops.features(geom, msb_d).cpu().numpy()
+        assert f.shape == G[name + "/features"].shape
+        assert np.array_equal(_bits(f), _bits(G[name + "/features"])), name  # reference bits
+        idx = torch.tensor([H * W - 1, 0, W, 3, H * W // 2], dtype=torch.int64, device=dev)
+        fi = ops.features(geom, msb_d, idx).cpu().numpy()
+        assert np.array_equal(_bits(fi), _bits(G[name + "/features"][idx.cpu().numpy()]))
+        li = ops.labels(img_d, K, idx).cpu().numpy()
+        assert np.array_equal(_bits(li), _bits(G[name + "/labels"][idx.cpu().numpy()]))
+
+
+# ---------------------------------------------------------------- a5
+
+@pytest.mark.parametrize("F,bc,C,nl,B", [(200, 64, 8, 2, 777), (18, 16, 3, 3, 65), (50, 32, 4, 1, 1),
+                                         (250, 256, 8, 2, 130), (7, 8, 1, 2, 64)])
+def test_forward_bit_exact_vs_oracle(dev, F, bc, C, nl, B):
+    rng = np.random.default_rng(F * 7 + bc)
+    params = _rand_params(rng, F, bc, C, nl, gain=3.0)
+    x = rng.uniform(-1, 1, (B, F)).astype(np.float32)
+    y = ops.forward(ops.make_net(F, bc, C, nl), torch.from_numpy(params).to(dev),
+                    torch.from_numpy(x).to(dev)).cpu().numpy()
+    yo = O.forward(params, F, bc, C, nl, x)
+    assert np.array_equal(_bits(y), _bits(yo))
+
+
+def test_forward_matches_reference_fixture(golden, dev):
+    G = golden["forward"]
+    for case in ("init", "wide", "embed"):
+        x, p, y_ref = G[case + "/x"], G[case + "/params"], G[case + "/y"]
+        net = ops.make_net(x.shape[1], 64, 8, 2)
+        y = ops.forward(net, torch.from_numpy(p).to(dev), torch.from_numpy(x).to(dev)).cpu().numpy()
+        np.testing.assert_allclose(y, y_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_model_forward_drop_in(golden, dev):
+    from LBDRNmodel import LBDRNModel
+    G = golden["forward"]
+    torch.manual_seed(19920517)
+    m = LBDRNModel(dim_in=200, dim_hidden=64, dim_out=8, num_layers=2)
+    assert np.array_equal(m.flat_parameters().numpy(), G["init/params"])
+    m = m.to(dev)
+    y = m(torch.from_numpy(G["init/x"]).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(y, G["init/y"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(Exception):
+        m(torch.from_numpy(G["init/x"]))  # CPU tensor: no CPU path
+
+
+# ---------------------------------------------------------------- a2+a5+a11, a9
+
+APPLY_CASES = [
+    # C, H, W, K, D, bc, nl, flags(coords, embed, colors, relative)
+    (8, 37, 150, 5, 2, 64, 2, (0, 0, 1, 1)),
+    (8, 16, 64, 5, 2, 64, 2, (0, 0, 1, 1)),
+    (3, 21, 33, 3, 1, 32, 1, (0, 0, 1, 1)),
+    (4, 19, 70, 6, 0, 64, 3, (0, 0, 1, 1)),
+    (1, 40, 41, 1, 3, 64, 2, (0, 0, 1, 1)),
+    (5, 9, 129, 5, 2, 128, 2, (0, 0, 1, 0)),
+    (8, 20, 66, 5, 2, 64, 2, (1, 1, 1, 1)),
+    (8, 18, 35, 5, 2, 64, 2, (1, 0, 1, 1)),
+    (4, 12, 65, 4, 2, 64, 2, (1, 1, 0, 1)),
+    (2, 3, 4, 6, 2, 64, 2, (0, 0, 1, 1)),
+    (8, 24, 20, 5, 2, 256, 2, (0, 0, 1, 1)),   # bc=256: generic path only
+]
+
+
+@pytest.mark.parametrize("case", APPLY_CASES)
+def test_decode_and_eval_bit_exact_vs_oracle(dev, case):
+    C, H, W, K, D, bc, nl, flags = case
+    rng = np.random.default_rng(sum(case[:7]))
+    cfg = _cfg(flags)
+    img = _image(rng, C, H, W)
+    msb_o, lab_o, mx = O.split_bits(img, K)
+    F = cfg.feature_dim(C, D)
+    params = _rand_params(rng, F, bc, C, nl, gain=2.0)
+    out_o, y_o = O.decode(msb_o, K, D, _ocfg(cfg), params, bc, nl, mx, want_y=True)
+    sse_o = O.eval_sse(msb_o, lab_o, D, _ocfg(cfg), params, bc, nl, mx)
+    img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb_o, dev)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+    net = ops.make_net(F, bc, C, nl)
+    p_d = torch.from_numpy(params).to(dev)
+    paths = [ops._lib.PATH_GENERIC] + ([ops._lib.PATH_MFMA] if bc <= 128 else [])
+    for path in paths:
+        out, y = ops.decode_fused(geom, net, msb_d, p_d, want_y=True, path=path)
+        assert np.array_equal(_bits(y.cpu().numpy()), _bits(y_o)), (case, path)
+        assert np.array_equal(ops.from_device_u16(out), out_o), (case, path)
+        sse = float(ops.eval_sse(geom, net, img_d, msb_d, p_d, path=path).item())
+        assert abs(sse - sse_o) <= 1e-11 * max(1.0, abs(sse_o)), (case, path, sse, sse_o)
+    if bc > 128:
+        with pytest.raises(ops._lib.LbdrnError):
+            ops.decode_fused(geom, net, msb_d, p_d, path=ops._lib.PATH_MFMA)
+
+
+def test_decode_matches_reference_fixture(golden, dev):
+    """decode.py:122-134 replayed with the reference's model: identical raster on the fixture."""
+    G = golden["decode"]
+    img, K, D = G["img"], int(G["K"]), int(G["D"])
+    msb, _, mx = O.split_bits(img, K)
+    C, H, W = img.shape
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(200, 64, 8, 2)
+    for path in (ops._lib.PATH_GENERIC, ops._lib.PATH_MFMA):
+        out, y = ops.decode_fused(geom, net, ops.to_device_u16(msb, dev),
+                                  torch.from_numpy(G["params"]).to(dev), want_y=True, path=path)
+        np.testing.assert_allclose(y.cpu().numpy(), G["y"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(ops.from_device_u16(out), G["image"])
+
+
+# ---------------------------------------------------------------- a7, a8
+
+def test_train_steps_match_reference_fixture(golden, dev):
+    """Teacher-forced updates vs torch autograd + torch.optim.Adam + StepLR run on the reference's
+    model/loss (tests/golden/make_golden.py): loss within 1e-5 relative at every step."""
+    T = golden["train"]
+    net = ops.make_net(200, 64, 8, 2)
+    p = torch.from_numpy(T["params0"].copy()).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    x, t = torch.from_numpy(T["x"]).to(dev), torch.from_numpy(T["t"]).to(dev)
+    for s in range(6):
+        b = torch.from_numpy(T["batches"][s]).to(dev)
+        loss, g = ops.train_step(net, x[b], t[b], p, m, v, s + 1, float(T[f"step{s}/lr"]))
+        ref = float(T[f"step{s}/loss"])
+        assert abs(float(loss.item()) - ref) <= RTOL_TRAIN * ref
+        gr = T[f"step{s}/grads"]
+        assert np.linalg.norm(g.cpu().numpy() - gr) <= 1e-5 * np.linalg.norm(gr)
+        pr = T[f"step{s}/params"]
+        assert np.linalg.norm(p.cpu().numpy() - pr) <= 1e-5 * np.linalg.norm(pr)
+    np.testing.assert_allclose(m.cpu().numpy(), T["exp_avg"], rtol=0, atol=1e-5 * np.abs(T["exp_avg"]).max())
+    np.testing.assert_allclose(v.cpu().numpy(), T["exp_avg_sq"], rtol=0, atol=1e-5 * np.abs(T["exp_avg_sq"]).max())
+
+
+@pytest.mark.parametrize("F,bc,C,nl,B", [(200, 64, 8, 2, 300), (18, 16, 3, 3, 64), (27, 32, 3, 1, 1000)])
+def test_train_step_vs_oracle(dev, F, bc, C, nl, B):
+    rng = np.random.default_rng(B + F)
+    p0 = _rand_params(rng, F, bc, C, nl)
+    x = rng.uniform(-1, 1, (B, F)).astype(np.float32)
+    t = rng.integers(0, 32, (B, C)).astype(np.float32) / 31
+    po, mo, vo = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    p = torch.from_numpy(p0.copy()).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    net = ops.make_net(F, bc, C, nl)
+    for s in range(3):
+        lo, go = O.train_step(po, mo, vo, F, bc, C, nl, x, t, 1e-3, s + 1)
+        loss, g = ops.train_step(net, torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev), p, m, v, s + 1, 1e-3)
+        assert abs(float(loss.item()) - lo) <= RTOL_TRAIN * lo
+        assert np.linalg.norm(g.cpu().numpy() - go) <= 2e-5 * np.linalg.norm(go)
+        assert np.linalg.norm(p.cpu().numpy() - po) <= 1e-5 * np.linalg.norm(po)
+
+
+def test_train_epoch_vs_oracle_sequence(dev):
+    """lbdrn_train_epoch (gather by permutation + update, short last batch) against the oracle run
+    step by step on oracle features/labels."""
+    rng = np.random.default_rng(5)
+    C, H, W, K, D, bc, nl, bs = 4, 23, 31, 5, 2, 64, 2, 200
+    cfg = FeatCfg()
+    img = _image(rng, C, H, W)
+    msb, lab, mx = O.split_bits(img, K)
+    feats = O.features(msb, D, _ocfg(cfg), mx)
+    F = feats.shape[1]
+    p0 = _rand_params(rng, F, bc, C, nl)
+    perm = rng.permutation(H * W).astype(np.int64)
+    po, mo, vo = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    losses_o = []
+    nsteps = (H * W + bs - 1) // bs
+    for s in range(nsteps):
+        b = perm[s * bs:(s + 1) * bs]
+        lo, _ = O.train_step(po, mo, vo, F, bc, C, nl, feats[b], lab[b], 1e-3, 7 + s + 1)
+        losses_o.append(lo)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+    net = ops.make_net(F, bc, C, nl)
+    p = torch.from_numpy(p0.copy()).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    losses = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+    ops.train_epoch(geom, net, ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev),
+                    torch.from_numpy(perm).to(dev), bs, p, m, v, 7, 1e-3, losses)
+    np.testing.assert_allclose(losses.cpu().numpy(), np.array(losses_o), rtol=RTOL_TRAIN)
+    assert np.linalg.norm(p.cpu().numpy() - po) <= 1e-5 * np.linalg.norm(po)
+
+
+def test_train_epoch_is_bitwise_reproducible(dev):
+    rng = np.random.default_rng(9)
+    C, H, W, K, D, bc, nl, bs = 8, 40, 48, 5, 2, 64, 2, 512
+    img = _image(rng, C, H, W)
+    msb, _, mx = O.split_bits(img, K)
+    F = 200
+    p0 = _rand_params(rng, F, bc, C, nl)
+    perm = torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(F, bc, C, nl)
+    outs = []
+    for _ in range(2):
+        p = torch.from_numpy(p0.copy()).to(dev)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        ops.train_epoch(geom, net, ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev), perm, bs, p, m, v, 0, 1e-3)
+        outs.append(p.cpu().numpy())
+    assert np.array_equal(_bits(outs[0]), _bits(outs[1]))

@@ -1,0 +1,204 @@
+"""Host-side logic and the C-ABI surface, no GPU needed."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    from lbdrn_hip import _lib
+    hdr = open(os.path.join(ROOT, "include", "lbdrn_hip.h")).read()
+    declared = set(re.findall(r"\b(lbdrn_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    L = ctypes.CDLL(_lib.lib_path())
+    for name in declared:
+        assert hasattr(L, name), name
+    assert _lib.lib().lbdrn_abi_version() == 1
+
+
+def test_geometry_helpers_without_device():
+    from lbdrn_hip import _lib
+    L = _lib.lib()
+    net = _lib.Net(200, 64, 8, 2)
+    assert L.lbdrn_param_count(ctypes.byref(net)) == 17544
+    net = _lib.Net(200, 256, 8, 2)
+    assert L.lbdrn_param_count(ctypes.byref(net)) == 119304
+    g = _lib.Geom(8, 16, 16, 5, 2, 100, 1, 1, 0, 0, None, None)
+    assert L.lbdrn_feature_dim(ctypes.byref(g)) == 200
+    g.P = 25
+    assert L.lbdrn_feature_dim(ctypes.byref(g)) == 250
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_compute_fails_loudly_without_gpu():
+    from lbdrn_hip import _lib, ops
+    assert _lib.lib().lbdrn_device_check() != 0
+    assert b"no CPU path" in _lib.lib().lbdrn_last_error() or b"HIP" in _lib.lib().lbdrn_last_error()
+    with pytest.raises(_lib.LbdrnError):
+        ops.split_bits(torch.zeros((1, 4, 4), dtype=torch.int16), 5)
+    from LBDRNmodel import LBDRNModel
+    with pytest.raises(_lib.LbdrnError):
+        LBDRNModel(8, 32, 2, 1)(torch.zeros(3, 8))
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "lbdrn-msic_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(base, f)).read()
+                code = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith(("//", "#", "*", "/*")) or l.lstrip().startswith("#include"))
+                if (re.search(r"^\s*(import|from)\s+(oracle|torch_port)\b", code, re.M)
+                        or re.search(r"#include.*oracle", code) or re.search(r"[\"']oracle[\"'/]", code)):
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_header_pack_unpack_vs_reference_bytes(golden):
+    from lbdrn_hip import container as c
+    G = golden["header"]
+    for i in range(4):
+        a = [int(v) for v in G[f"h{i}/args"]]
+        nn, bb = [int(v) for v in G[f"h{i}/nn"]], [int(v) for v in G[f"h{i}/base"]]
+        raw = c.pack_header(a[0], a[1], a[2], a[3], a[4], a[5], a[6], nn, bb)
+        assert raw == G[f"h{i}/bytes"].tobytes()
+        got = c.unpack_header(raw)
+        assert list(got[:8]) + got[8] + got[9] == [int(v) for v in G[f"h{i}/parsed"]]
+    for bad in (dict(bc=48), dict(K=16), dict(D=16), dict(nl=16), dict(width=65536), dict(split_ratio=6)):
+        kw = dict(split_ratio=1, width=8, height=8, K=5, bc=64, nl=2, D=2)
+        kw.update(bad)
+        t = kw["split_ratio"] ** 2
+        with pytest.raises((ValueError, OverflowError)):
+            c.pack_header(kw["split_ratio"], kw["width"], kw["height"], kw["K"], kw["bc"], kw["nl"], kw["D"],
+                          [1] * t, [1] * t)
+    with pytest.raises(OverflowError):
+        c.pack_header(1, 8, 8, 5, 64, 2, 2, [1 << 24], [1])
+
+
+def test_model_init_and_rng_position_vs_reference(golden):
+    from LBDRNmodel import LBDRNModel
+    G = golden["init"]
+    for name in ("bc64_nl2", "bc16_nl3", "bc32_nl1"):
+        F, bc, C, nl = [int(v) for v in G[name + "/dims"]]
+        torch.manual_seed(19920517)
+        m = LBDRNModel(dim_in=F, dim_hidden=bc, dim_out=C, num_layers=nl)
+        assert list(m.state_dict().keys()) == [str(k) for k in G[name + "/keys"]]
+        assert np.array_equal(m.flat_parameters().numpy(), G[name + "/params"])
+        nxt = [torch.empty((), dtype=torch.int64).random_().item() for _ in range(2)]
+        assert nxt == [int(v) for v in G[name + "/next_draws"]]
+
+
+def test_sampler_replays_dataloader_draw_order():
+    """train, eval, train, eval ... iterators of a real DataLoader vs lbdrn_hip.sampler."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from lbdrn_hip import sampler
+    n, bs, epochs = 103, 16, 3
+    ds = TensorDataset(torch.arange(n))
+    torch.manual_seed(7)
+    loader = DataLoader(ds, batch_size=bs, shuffle=True)
+    want = []
+    for _ in range(epochs):
+        want.append(torch.cat([b[0] for b in loader]))   # trainer pass
+        for _ in loader:                                  # evaluator pass (order irrelevant)
+            pass
+    torch.manual_seed(7)
+    st = sampler.PermutationStream(n, epochs, 1, workers=2, pin=False)
+    for e in range(1, epochs + 1):
+        assert torch.equal(st.get(e), want[e - 1])
+    assert sampler.epoch_plan(1, 1) == [("train", 1)]      # epochs == 1: no evaluation (encode.py:100)
+    assert sampler.epoch_plan(4, 2) == [("train", 1), ("train", 2), ("eval", 2), ("train", 3), ("train", 4), ("eval", 4)]
+    # after the stream the global generator sits where the DataLoader run left it
+    a = torch.empty((), dtype=torch.int64).random_().item()
+    torch.manual_seed(7)
+    for _ in range(epochs):
+        for _ in loader:
+            pass
+        for _ in loader:
+            pass
+    assert a == torch.empty((), dtype=torch.int64).random_().item()
+
+
+def test_lr_schedule_equals_torch_steplr():
+    from lbdrn_hip.codec import lr_schedule
+    for epochs in (1, 2, 3, 10, 11):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1e-3)
+        sch = torch.optim.lr_scheduler.StepLR(opt, step_size=max(1, int(epochs / 3)), gamma=0.1)
+        want = []
+        for _ in range(epochs):
+            want.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        assert lr_schedule(1e-3, epochs) == want
+
+
+def test_positional_tables_equal_reference_features(golden):
+    from lbdrn_hip.features import FeatCfg, pos_tables
+    G = golden["features"]
+    f = G["G_embed/features"].reshape(12, 10, 250)
+    rt, ct = pos_tables(12, 10, FeatCfg(use_coordinates=True, embedding=True))
+    assert np.array_equal(rt, f[:, 0, :25]) and np.array_equal(ct, f[0, :, 25:50])
+    f = G["F_coords/features"].reshape(12, 10, 202)
+    rt, ct = pos_tables(12, 10, FeatCfg(use_coordinates=True))
+    assert np.array_equal(rt[:, 0], f[:, 0, 0]) and np.array_equal(ct[:, 0], f[0, :, 1])
+
+
+def test_payload_round_trips_and_precision_model():
+    from lbdrn_hip import container as c
+    rng = np.random.default_rng(0)
+    w = rng.normal(0, 0.1, 17544).astype(np.float32)
+    for prec in (16, 20, 32, 8):
+        q = c.decode_weights(c.encode_weights(w, prec))
+        assert np.array_equal(q.view(np.uint32), c.truncate_precision(w, prec).view(np.uint32))
+    assert np.all(c.truncate_precision(w, 16).view(np.uint32) & 0xFFFF == 0)
+    for dt, hi in ((np.uint16, 2000), (np.uint8, 255)):
+        x = rng.integers(0, hi, (3, 37, 41)).astype(dt)
+        y = c.decode_base(c.encode_base(x))
+        assert y.dtype == dt and np.array_equal(x, y)
+    m = __import__("LBDRNmodel").LBDRNModel(10, 8, 2, 2)
+    flat = c.flatten_state(m.state_dict())
+    sd = c.unflatten_state(flat, m.state_dict())
+    assert all(torch.equal(sd[k], v) for k, v in m.state_dict().items())
+
+
+def test_raster_io_round_trip(tmp_path):
+    from lbdrn_hip import raster_io as r
+    rng = np.random.default_rng(1)
+    for C, dt in ((8, np.uint16), (1, np.uint8), (3, np.float32)):
+        a = rng.uniform(0, 250, (C, 13, 17)).astype(dt)
+        p = str(tmp_path / f"t{C}.tif")
+        r.write_raster(p, a)
+        b = r.read_raster(p)
+        assert np.array_equal(b.reshape(a.shape), a) and b.dtype == a.dtype
+    with pytest.raises(ValueError):
+        r.write_raster(str(tmp_path / "x.tif"), np.zeros((1, 2, 2), np.int64))
+
+
+def test_tile_windows_cover_image():
+    from LBDRNdataset import tile_windows
+    cov = np.zeros((31, 50), int)
+    for i, j, x0, y0, w, h in tile_windows(50, 31, 3):
+        cov[y0:y0 + h, x0:x0 + w] += 1
+    assert (cov == 1).all()
+
+
+def test_torch_port_forms_agree_and_fit_something():
+    """oracle/torch_port.py: DataLoader form and index_select form walk the same RNG stream."""
+    import torch_port as TP
+    from lbdrn_hip.synth import synthetic_tile
+    img = synthetic_tile(3, 4, 24, 32)
+    torch.manual_seed(19920517)
+    a = TP.fit(img, 5, 1, 16, 2, 1e-3, 128, 3, faithful=True)
+    torch.manual_seed(19920517)
+    b = TP.fit(img, 5, 1, 16, 2, 1e-3, 128, 3, faithful=False)
+    assert np.array_equal(a["params"], b["params"]) and a["best_epoch"] == b["best_epoch"]
+    rec = TP.apply(a["msb"], a["params"], 5, 1, 16, 2)
+    assert np.array_equal(rec >> 5, img >> 5)
+    import oracle as O
+    rec_o = O.decode(a["msb"], 5, 1, O.FeatCfg(), a["params"], 16, 2)
+    assert (rec_o != rec).mean() < 1e-3   # canonical arithmetic vs torch: boundary flips only
