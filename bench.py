@@ -88,7 +88,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     # one training epoch on scratch weights
     perm = torch.randperm(N, device=img_d.device)
     pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
-    tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device)
+    tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path)
     t_train = event_time_ms(lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0,
                                                     1e-6, None, path, tws), stream, 1)
     nsteps = (N + a.bs - 1) // a.bs

@@ -116,6 +116,13 @@ int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *im
  * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
  * short (no drop_last, encode.py:69). */
 size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
+/* Once per image, before the first lbdrn_train_epoch on this workspace: builds the per-image state
+ * the fused path keeps in the workspace (the [N][F+C] feature|label row matrix that replaces the
+ * reference's host-side LBDRNDataset tensors, LBDRNdataset.py:141-142).  The workspace contents
+ * must then be left untouched between the epochs of that image.  No-op for the generic path. */
+int lbdrn_train_prepare(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
+                        const uint16_t *msb, int32_t batch_size, void *workspace,
+                        size_t workspace_bytes, int32_t path, void *stream);
 int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
                       const uint16_t *msb, const int64_t *perm, int64_t n, int32_t batch_size,
                       float *params, float *exp_avg, float *exp_avg_sq, int64_t adam_step0,

@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             for (int e = tid; e < total; e += APPLY_THREADS) {
                 int c = e / plane, r = e - c * plane;
                 int sy = r / p.SW, sx = r - sy * p.SW;
-                int yy = reflect_idx(y0 + sy - D, g.H), xx = reflect_idx(x0 + sx - D, g.W);
+                int yy = reflect_fast(y0 + sy - D, g.H), xx = reflect_fast(x0 + sx - D, g.W);
                 tile[e] = (float)A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx] / maxf;
             }
         }

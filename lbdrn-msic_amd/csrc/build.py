@@ -25,14 +25,15 @@ def stale():
     return any(os.path.getmtime(os.path.join(HERE, f)) > t for f in SRCS + HDRS + ["build.py"])
 
 
-def build(force=False, extra=()):
-    if not force and not stale():
+def build(force=False, extra=(), out=None):
+    out = out or OUT
+    if out == OUT and not force and not stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in SRCS:
-        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        obj = os.path.join(HERE, src.replace(".hip", ".o" if out == OUT else ".diag.o"))
         objs.append(obj)
         cmd = [hipcc, "-c"] + [f for f in FLAGS if f != "-shared"] + list(extra) + \
               ["-o", obj, os.path.join(HERE, src)]
@@ -40,9 +41,13 @@ def build(force=False, extra=()):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
-    return OUT
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--stamps" in sys.argv:  # diagnostic build with in-kernel s_memtime stamps (never benchmarked)
+        print(build(force=True, extra=["-DLBDRN_TRAIN_STAMPS"],
+                    out=os.path.join(os.path.dirname(HERE), "liblbdrn_hip_stamps.so")))
+    else:
+        print(build(force="--force" in sys.argv))

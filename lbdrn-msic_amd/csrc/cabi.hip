@@ -8,6 +8,8 @@ namespace lbdrn {
 const char* last_error();
 bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net);
 size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
+int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
+                       const uint16_t* msb, int bs, void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
@@ -175,6 +177,26 @@ size_t lbdrn_train_workspace(const lbdrn_geom* g, const lbdrn_net* net, int32_t 
     size_t a = generic_train_workspace(*net, batch_size);
     size_t b = mfma_train_supported(*g, *net) ? mfma_train_workspace(*g, *net, batch_size) : 0;
     return a > b ? a : b;
+}
+
+int lbdrn_train_prepare(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t* img,
+                        const uint16_t* msb, int32_t batch_size, void* workspace, size_t workspace_bytes,
+                        int32_t path, void* stream)
+{
+    if (int rc = check_geom(g)) return rc;
+    if (int rc = check_net(net)) return rc;
+    if (int rc = net_matches(g, net)) return rc;
+    LBDRN_REQUIRE(img && msb && batch_size >= 1, "null pointer or bad batch size");
+    LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
+    NEED_DEVICE();
+    const bool ok = mfma_train_supported(*g, *net);
+    if (path == LBDRN_PATH_MFMA && !ok) {
+        set_error("fused MFMA train kernel does not support this shape");
+        return LBDRN_E_UNSUPPORTED;
+    }
+    if (ok && path != LBDRN_PATH_GENERIC)
+        return mfma_train_prepare(*g, *net, img, msb, batch_size, workspace, workspace_bytes, (hipStream_t)stream);
+    return 0;
 }
 
 int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t* img,

@@ -127,4 +127,13 @@ LBDRN_DEV int reflect_idx(int i, int n)
     return (i < n) ? i : period - i;
 }
 
+// same map without the integer modulo when one reflection suffices (|offset| < n, i.e. D < size)
+LBDRN_DEV int reflect_fast(int i, int n)
+{
+    int r = i < 0 ? -i : i;
+    r = r >= n ? 2 * (n - 1) - r : r;
+    if (r < 0 || r >= n) r = reflect_idx(i, n);
+    return r;
+}
+
 }  // namespace lbdrn

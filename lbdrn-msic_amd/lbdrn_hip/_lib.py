@@ -3,7 +3,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(os.path.dirname(_HERE), "liblbdrn_hip.so")
+# LBDRN_HIP_LIB selects another build of the same ABI (e.g. the diagnostic liblbdrn_hip_stamps.so)
+_LIB_PATH = os.environ.get("LBDRN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "liblbdrn_hip.so")
 
 PATH_AUTO, PATH_GENERIC, PATH_MFMA = 0, 1, 2
 
@@ -46,6 +47,7 @@ SIGNATURES = {
     "lbdrn_decode_fused": (ctypes.c_int, [_GP, _NP, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "lbdrn_eval_sse": (ctypes.c_int, [_GP, _NP, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp]),
     "lbdrn_train_workspace": (_sz, [_GP, _NP, _i32]),
+    "lbdrn_train_prepare": (ctypes.c_int, [_GP, _NP, _vp, _vp, _i32, _vp, _sz, _i32, _vp]),
     "lbdrn_train_epoch": (ctypes.c_int, [_GP, _NP, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64,
                                          _dbl, _vp, _vp, _sz, _i32, _vp]),
     "lbdrn_train_step": (ctypes.c_int, [_NP, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _dbl, _i32, _vp,

@@ -82,7 +82,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     lrs = lr_schedule(lr, epochs)
     steps_per_epoch = (N + batch_size - 1) // batch_size
     losses = torch.zeros((epochs, steps_per_epoch), dtype=torch.float32, device=dev) if keep_losses else None
-    train_ws = ops.TrainWorkspace(geom, net, batch_size, dev)
+    train_ws = ops.TrainWorkspace(geom, net, batch_size, dev).prepare(img_d, msb_d, path)   # a2-a4
     apply_ws = ops.ApplyWorkspace(geom, net, dev)
     best_params = params.clone()
     best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)   # encode.py:91

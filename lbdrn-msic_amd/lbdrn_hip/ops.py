@@ -147,9 +147,21 @@ def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None):
 
 
 class TrainWorkspace:
+    """Device scratch of the training path; prepare() builds the per-image state in it once."""
+
     def __init__(self, geom, net, batch_size, device):
+        self.geom, self.net, self.batch_size = geom, net, batch_size
         self.nbytes = lib().lbdrn_train_workspace(ctypes.byref(geom.c), ctypes.byref(net), batch_size)
         self.buf = torch.empty(max(self.nbytes, 1), dtype=torch.uint8, device=device)
+        self.prepared_for = None
+
+    def prepare(self, img, msb, path=PATH_AUTO):
+        img, msb = _u16(img.contiguous()), _u16(msb.contiguous())
+        check(lib().lbdrn_train_prepare(ctypes.byref(self.geom.c), ctypes.byref(self.net), _ptr(img),
+                                        _ptr(msb), self.batch_size, _ptr(self.buf), self.nbytes, path,
+                                        _stream()))
+        self.prepared_for = (img.data_ptr(), path)
+        return self
 
 
 def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_sq, adam_step0, lr,
@@ -161,7 +173,10 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
     assert perm.dtype == torch.int64 and perm.is_contiguous()
     for t in (params, exp_avg, exp_avg_sq):
         assert t.dtype == torch.float32 and t.is_contiguous()
-    ws = ws or TrainWorkspace(geom, net, batch_size, img.device)
+    if ws is None:
+        ws = TrainWorkspace(geom, net, batch_size, img.device).prepare(img, msb, path)
+    if ws.prepared_for != (img.data_ptr(), path):
+        raise _lib.LbdrnError("TrainWorkspace.prepare(img, msb, path) must run once for this image first")
     check(lib().lbdrn_train_epoch(ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
                                   _ptr(perm), perm.numel(), batch_size, _ptr(params), _ptr(exp_avg),
                                   _ptr(exp_avg_sq), adam_step0, float(lr), _ptr(losses), _ptr(ws.buf),

@@ -1,0 +1,77 @@
+// Diagnostic microbenchmark (not part of the product): cycles per v_mfma_f32_16x16x4_f32 /
+// v_mfma_f32_32x32x2_f32 for 1, 2, 4 independent accumulator chains, 1 or 2 waves per SIMD.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int CHAINS>
+__global__ void k16(float* out, unsigned long long* cyc, int iters)
+{
+    f32x4 acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) acc[c] = {0.f, 0.f, 0.f, 0.f};
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float s = 0;
+    for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <int CHAINS>
+__global__ void k32(float* out, unsigned long long* cyc, int iters)
+{
+    f32x16 acc[CHAINS];
+    for (int c = 0; c < CHAINS; ++c) for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = 1.0f + threadIdx.x * 1e-4f;
+    unsigned long long t0, t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+    }
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float s = 0;
+    for (int c = 0; c < CHAINS; ++c) for (int r = 0; r < 16; ++r) s += acc[c][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+template <class K>
+void run(const char* name, K kern, int threads, int chains, int nblk)
+{
+    float* out; unsigned long long* cyc;
+    hipMalloc(&out, sizeof(float) * threads * nblk); hipMalloc(&cyc, 8 * nblk);
+    const int iters = 2000;
+    kern<<<nblk, threads>>>(out, cyc, iters);
+    kern<<<nblk, threads>>>(out, cyc, iters);
+    hipDeviceSynchronize();
+    unsigned long long h[1024]; hipMemcpy(h, cyc, 8 * nblk, hipMemcpyDeviceToHost);
+    double m = 0; for (int i = 0; i < nblk; ++i) m += h[i]; m /= nblk;
+    int waves_per_simd = threads / 256;
+    printf("%-10s threads=%4d chains=%d blocks=%4d : %.1f cycles per MFMA per wave, %.1f per MFMA per SIMD\n", name, threads,
+           chains, nblk, m / (iters * 8.0 * chains), m / (iters * 8.0 * chains) / (waves_per_simd ? waves_per_simd : 1));
+    hipFree(out); hipFree(cyc);
+}
+int main()
+{
+    for (int nblk : {1, 256}) {
+        run("16x16x4", k16<1>, 256, 1, nblk);
+        run("16x16x4", k16<2>, 256, 2, nblk);
+        run("16x16x4", k16<4>, 256, 4, nblk);
+        run("16x16x4", k16<1>, 512, 1, nblk);
+        run("16x16x4", k16<2>, 512, 2, nblk);
+        run("32x32x2", k32<1>, 256, 1, nblk);
+        run("32x32x2", k32<2>, 256, 2, nblk);
+        run("32x32x2", k32<2>, 512, 2, nblk);
+    }
+    return 0;
+}
