@@ -143,14 +143,15 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-    from lbdrn_hip import codec, ops
+    from lbdrn_hip import codec, ops, shard
     from lbdrn_hip.synth import synthetic_tile
     path = {"auto": ops._lib.PATH_AUTO, "generic": ops._lib.PATH_GENERIC, "mfma": ops._lib.PATH_MFMA}[a.path]
 
-    # tiles of this rank, resident in HBM before the clock starts (image index unique per rank/step)
+    # the job is (warmup + steps) * world images, dealt round-robin; this rank's tiles are
+    # resident in HBM before the clock starts
     total = a.warmup + a.steps
-    tiles = [ops.to_device_u16(synthetic_tile(rank * total + i, a.bands, a.height, a.width), dev)
-             for i in range(total)]
+    mine = shard.assign(total * world, rank, world)
+    tiles = [ops.to_device_u16(synthetic_tile(i, a.bands, a.height, a.width), dev) for i in mine]
     torch.cuda.synchronize()
 
     def barrier():
@@ -168,23 +169,14 @@ def main():
         fit, rec = one_image(codec, ops, tiles[i], a, path)
         last = (fit, rec, tiles[i])
     barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
 
     # per-image metric record of the last tile (after the clock): MSE / PSNR of the reconstruction
     fit, rec, img_d = last
     diff = (img_d.view(torch.int16).to(torch.int32) & 0xFFFF).float() - (rec.to(torch.int32) & 0xFFFF).float()
     mse = float((diff * diff).mean().item())
-    rec_t = torch.tensor([rank, mse, float(fit.mse_log[:, 0].min().item())], dtype=torch.float64, device=dev)
-    if world > 1:
-        gathered = [torch.zeros_like(rec_t) for _ in range(world)]
-        dist.all_gather(gathered, rec_t)   # the only data the ranks exchange
-        records = [g.tolist() for g in gathered]
-    else:
-        records = [rec_t.tolist()]
+    # [image index, reconstruction MSE, best evaluation MSE]: the only data the ranks exchange
+    records = shard.gather_records([[float(mine[-1]), mse, float(fit.mse_log[:, 0].min().item())]], 3, dev)
 
     if rank == 0:
         px = a.height * a.width

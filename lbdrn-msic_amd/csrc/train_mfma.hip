@@ -7,27 +7,33 @@
 //  * a minibatch is 8192 rows and 646 MFLOP: 4.1 us of the whole chip at the f32 MFMA peak.  The
 //    step is a serial chain (the next step needs the updated weights), so it is latency-bound: the
 //    batch is cut into 256 workgroups of 32 samples -- one per CU -- and every layer of those 32
-//    samples is split over the CU's 4 SIMDs: wave w owns hidden neurons 16w..16w+15 for both
-//    16-sample column tiles (v_mfma_f32_16x16x4_f32, two independent accumulators per wave).
-//  * activations and their gradients sit in LDS as [sample][unit] with a row pitch = 2 (mod 32)
-//    floats, which makes the forward B-operand reads conflict-free and the weight-gradient reads
-//    2-way; weights are never staged in LDS: every A operand comes straight from L2 into VGPRs,
-//    prefetched at kernel start (layer 0 in double-buffered chunks) in "fragment order" so that a
-//    wave-wide load is one 256-byte line.  The kernel runs one wave per SIMD with up to 512 VGPRs.
+//    samples is split over 8 waves: wave (w, st) owns hidden neurons 16w..16w+15 of the 16-sample
+//    column tile st (v_mfma_f32_16x16x4_f32).  Two waves share each SIMD so that one wave's
+//    MFMAs cover the other's operand reads and bookkeeping (a wave issues in order).
+//  * "quarter-K" operand order: in one 16x16x4 MFMA the four k slots belong to the four 16-lane
+//    quarters of the wave; any assignment of k indices to slots is legal as long as A and B
+//    agree.  Quarter q takes the contiguous range k = q*L .. q*L+L-1 (L = K/4), so a lane's B
+//    operands for ALL steps of a layer are L contiguous floats of one LDS row: a handful of
+//    ds_read_b128 instead of one ds_read_b32 per MFMA (measured: with b32 operand reads the step
+//    spent 55-86 cycles per 32-cycle MFMA).  The weights are packed to match.
+//  * activations and their gradients sit in LDS twice, [sample][unit] for the forward / backward
+//    products and [unit][sample] for the weight-gradient products, all rows 16-byte aligned with an
+//    odd number of 16-byte chunks per row.  Weights never touch LDS: every A operand is prefetched
+//    L2 -> VGPR at kernel start, in fragment order (one 256-byte line per wave load).
 //  * cos(30 z) needed by the backward pass is kept in registers: the wave that produced a tile of
 //    z is the wave that later receives the matching tile of dL/dh, in the same lane/register slots.
-//  * weight gradients are sums over the minibatch: each workgroup writes its partial (70 KB) to a
-//    slab; k_reduce_adam adds the 256 slabs in index order (bitwise reproducible, no atomics).
+//  * weight gradients are sums over the minibatch: each workgroup writes its partial in TILE order
+//    (an accumulator tile is 64 lanes x 16 contiguous bytes = one 1 KB wave store, no LDS staging);
+//    k_reduce_adam adds the 256 slabs in index order (bitwise reproducible, no atomics) and maps
+//    tile order back to state_dict order for the Adam update.
 //  * the minibatch gather reads whole rows of a [N][F+C] float32 matrix (features | labels) that
 //    lbdrn_train_prepare materialises once per image: 3.5 GB for a 2048^2x8 tile, nothing on a
 //    288 GB part, and a random 832-byte row is 7 full cache lines, where gathering the 5x5xC window
 //    from a pixel plane moves 2-4x the bytes in partial lines (measured: 5.9 us of a 22 us step).
 //    The evaluation / decode passes never use this matrix (they stage windows through LDS).
-//  * each workgroup's gradient is assembled in LDS in parameter order and leaves as full 1 KB
-//    wave-stores; per-tile strided dword stores cost 6.9 us of the step before.
 //
 // Training parity is a tolerance contract (1e-5 relative on the loss), not a bit
-// pattern: the batch sum order differs from the generic kernels and from torch.
+// pattern: the summation order differs from the generic kernels and from torch.
 #include <cmath>
 #include <vector>
 
@@ -40,46 +46,38 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TB = 32;       // samples per workgroup
 constexpr int TBC = 64;      // hidden width this kernel is built for
-constexpr int HPITCH = 66;   // [sample][64] activations, pitch = 2 (mod 32)
-constexpr int OPITCH = 18;   // [sample][16] output-layer gradient
-constexpr int RED_SLICES = 16;
+constexpr int HP = 68;       // [sample][64] rows: 17 chunks of 16 B
+constexpr int TP = 36;       // [unit][32 samples] rows: 9 chunks of 16 B
+constexpr int OP = 20;       // [sample][16 channel slots] rows: 5 chunks
+constexpr int RED_SLICES = 32;  // workgroup slices per reduce block
+constexpr int RED_LANES = 256 / RED_SLICES;  // float4 lanes per reduce block
+constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample tile st = 0..1)
 
 struct TrainPlan {
-    int CH;                    // layer-0 prefetch chunk (MFMA steps)
-    int S0;                    // layer-0 MFMA steps, padded to a multiple of CH
-    int FP;                    // X row pitch (floats), = 2 (mod 32), >= 4*S0 and >= 16*NT0
+    int LQ;                    // layer-0 quarter length = MFMA steps of layer 0 (F <= 4*LQ)
+    int XP;                    // X row pitch = 4*LQ + 4 floats
     int NT0;                   // 16-wide feature tiles of dW0 = ceil(F/16)
     int RP;                    // row pitch of the materialised [N][RP] matrix: F features, C labels, pad to x4
-    int NPP;                   // slab pitch: NP padded to a multiple of 64 floats
-    int side, ncolor;
     int64_t NP;
     int64_t offW[5], offB[5];  // canonical parameter offsets per layer (index nl = last layer)
     int pk_w0, pk_wh, pk_wl, pack_floats;  // fragment-order buffer (floats)
-    int lds_x, lds_h, lds_z, lds_zo, lds_yx, lds_red, lds_g, lds_floats;
+    int sl_hid, sl_out, sl_bias, slab_floats;  // slab (tile order) section starts, in floats
+    int lds_x, lds_xt, lds_h, lds_ht, lds_z, lds_zt, lds_zo, lds_zot, lds_pix, lds_red, lds_floats;
 };
 
 static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan* out)
 {
     if (net.bc != TBC || net.nl < 1 || net.nl > 3 || net.C > 16 || net.F < 1) return false;
     TrainPlan p;
-    const int s0 = (net.F + 3) / 4;
-    int best_ch = 8, best_pad = 1 << 30;
-    for (int ch : {10, 8}) {
-        int pad = (s0 + ch - 1) / ch * ch;
-        if (pad < best_pad) { best_pad = pad; best_ch = ch; }
-    }
-    p.CH = best_ch;
-    p.S0 = best_pad;
-    p.NT0 = (net.F + 15) / 16;
     p.RP = (net.F + net.C + 3) / 4 * 4;
-    int need = std::max(std::max(4 * p.S0, 16 * p.NT0), p.RP);
-    p.FP = (need + 29) / 32 * 32 + 2;
-    if (p.FP < need) p.FP += 32;
-    p.side = 2 * g.D + 1;
-    p.ncolor = net.F - 2 * g.P;
-    if (p.ncolor < 0) return false;
+    p.LQ = 0;
+    for (int lq : {16, 32, 52, 64})
+        if (net.F <= 4 * lq && p.RP <= 4 * lq + 4) { p.LQ = lq; break; }
+    if (!p.LQ) return false;
+    p.XP = 4 * p.LQ + 4;
+    p.NT0 = (net.F + 15) / 16;
+    if (16 * p.NT0 > p.XP) return false;
     p.NP = param_count(net);
-    p.NPP = (int)((p.NP + 63) / 64 * 64);
     int64_t o = 0;
     for (int l = 0; l < net.nl; ++l) {
         int nin = l ? TBC : net.F;
@@ -89,20 +87,26 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.offW[net.nl] = o; o += (int64_t)net.C * TBC;
     p.offB[net.nl] = o;
     int k = 0;
-    p.pk_w0 = k; k += 4 * p.S0 * 64;
+    p.pk_w0 = k; k += 4 * p.LQ * 64;
     p.pk_wh = k; k += (net.nl - 1) * 4 * 16 * 64;
     p.pk_wl = k; k += 16 * 64;
     p.pack_floats = k;
+    int s = 4 * p.NT0 * 256;
+    p.sl_hid = s; s += (net.nl - 1) * 16 * 256;
+    p.sl_out = s; s += 4 * 256;
+    p.sl_bias = s; s += net.nl * TBC + 16;
+    p.slab_floats = (s + 63) / 64 * 64;  // multiple of 4*RED_LANES
     int f = 0;
-    p.lds_x = f; f += TB * p.FP;
-    p.lds_h = f; f += net.nl * TB * HPITCH;
-    p.lds_z = f; f += net.nl * TB * HPITCH;
-    p.lds_zo = f; f += TB * OPITCH;
-    p.lds_yx = f; f += 2 * TB;
-    f = (f + 1) & ~1;
+    p.lds_x = f; f += TB * p.XP;
+    p.lds_xt = f; f += 16 * p.NT0 * TP;
+    p.lds_h = f; f += net.nl * TB * HP;
+    p.lds_ht = f; f += net.nl * TBC * TP;
+    p.lds_z = f; f += net.nl * TB * HP;
+    p.lds_zt = f; f += net.nl * TBC * TP;
+    p.lds_zo = f; f += TB * OP;
+    p.lds_zot = f; f += 16 * TP;
+    p.lds_pix = f; f += TB;
     p.lds_red = f; f += 16;
-    f = (f + 3) & ~3;
-    p.lds_g = f; f += p.NPP;
     p.lds_floats = f;
     if ((size_t)f * 4 > 160 * 1024) return false;
     *out = p;
@@ -126,7 +130,7 @@ static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, 
     L.off_rows = o; o += align_up((size_t)g.H * g.W * p.RP * sizeof(float), 256);
     L.off_pack = o; o += align_up((size_t)p.pack_floats * sizeof(float), 256);
     const size_t nwg = (size_t)(bs + TB - 1) / TB;
-    L.off_slab = o; o += align_up(nwg * (size_t)p.NPP * sizeof(float), 256);
+    L.off_slab = o; o += align_up(nwg * (size_t)p.slab_floats * sizeof(float), 256);
     L.off_loss = o; o += align_up(nwg * sizeof(double), 256);
     L.total = o;
     return L;
@@ -176,26 +180,53 @@ __global__ void __launch_bounds__(256)
     rows[e] = v;
 }
 
-// canonical parameter index -> position in the fragment-order buffer (or -1: not packed)
+// canonical parameter index -> position in the fragment-order buffer (or -1: not packed).
+// Quarter-K order: MFMA step s of lane quarter q multiplies k = q*L + s.
 __device__ __forceinline__ int frag_pos(int64_t idx, const TrainPlan& p, int F, int nl, int C)
 {
     if (idx < p.offB[0]) {  // W0[n][k]
         int n = (int)(idx / F), k = (int)(idx - (int64_t)n * F);
-        return p.pk_w0 + (((n >> 4) * p.S0 + (k >> 2)) * 64 + (k & 3) * 16 + (n & 15));
+        int q = k / p.LQ, s = k - q * p.LQ;
+        return p.pk_w0 + (((n >> 4) * p.LQ + s) * 64 + q * 16 + (n & 15));
     }
     for (int l = 1; l < nl; ++l) {
         if (idx >= p.offW[l] && idx < p.offB[l]) {  // W_l[n][k]
             int e = (int)(idx - p.offW[l]);
             int n = e >> 6, k = e & 63;
-            return p.pk_wh + ((((l - 1) * 4 + (n >> 4)) * 16 + (k >> 2)) * 64 + (k & 3) * 16 + (n & 15));
+            return p.pk_wh + ((((l - 1) * 4 + (n >> 4)) * 16 + (k & 15)) * 64 + (k >> 4) * 16 + (n & 15));
         }
     }
     if (idx >= p.offW[nl] && idx < p.offB[nl]) {  // W_last[c][k]
         int e = (int)(idx - p.offW[nl]);
         int c = e >> 6, k = e & 63;
-        return p.pk_wl + ((k >> 2) * 64 + (k & 3) * 16 + c);
+        return p.pk_wl + ((k & 15) * 64 + (k >> 4) * 16 + c);
     }
     return -1;
+}
+
+// slab element (tile order) -> canonical parameter index (or -1: padding)
+__device__ __forceinline__ int64_t slab_to_param(int e, const TrainPlan& p, int F, int nl, int C)
+{
+    if (e >= p.sl_bias) {
+        int b = e - p.sl_bias;
+        if (b < nl * TBC) return p.offB[b >> 6] + (b & 63);
+        int ch = b - nl * TBC;
+        return ch < C ? p.offB[nl] + ch : -1;
+    }
+    const int tile = e >> 8, lane = (e >> 2) & 63, r = e & 3;
+    const int row = 4 * (lane >> 4) + r, col = lane & 15;
+    if (e < p.sl_hid) {
+        int w = tile / p.NT0, nt = tile - w * p.NT0;
+        int k = 16 * nt + col;
+        return k < F ? p.offW[0] + (int64_t)(16 * w + row) * F + k : -1;
+    }
+    if (e < p.sl_out) {
+        int t2 = tile - 4 * p.NT0;
+        int l = 1 + (t2 >> 4), w = (t2 >> 2) & 3, nt = t2 & 3;
+        return p.offW[l] + (int64_t)(16 * w + row) * TBC + 16 * nt + col;
+    }
+    int w = tile - (p.sl_out >> 8);
+    return row < C ? p.offW[nl] + (int64_t)row * TBC + 16 * w + col : -1;
 }
 
 __global__ void __launch_bounds__(256)
@@ -207,32 +238,60 @@ __global__ void __launch_bounds__(256)
     if (pos >= 0) packed[pos] = params[idx];
 }
 
-// g[idx] = sum over workgroups (index order within a slice, slices in order) of slab[wg][idx];
+// g = sum over workgroups (index order within a slice, slices in order) of slab[wg][e];
 // torch Adam (torch/optim/adam.py single-tensor path: lerp_, mul_/addcmul_, addcdiv_); refresh the
-// fragment copy.  Block = 16 float4 lanes (64 parameters) x 16 workgroup slices.
+// fragment copy.  Block = RED_LANES float4 lanes x RED_SLICES workgroup slices.  While the slab reads are
+// in flight the block also touches its share of the NEXT minibatch's index slice and feature rows, so
+// that the following train kernel finds them in the Infinity Cache instead of HBM.
 __global__ void __launch_bounds__(256)
     k_reduce_adam(const float* __restrict__ slabs, int nwg, TrainPlan p, int F, int nl, int C,
                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                   float* __restrict__ packed, float step_size, float bc2_sqrt,
-                  const double* __restrict__ loss_part, double loss_count, float* loss_out)
+                  const double* __restrict__ loss_part, double loss_count, float* loss_out,
+                  const int64_t* __restrict__ next_perm, int next_n, const float* __restrict__ rows, int64_t npix)
 {
-    __shared__ float4 part[RED_SLICES][16];
-    const int l16 = threadIdx.x & 15, slice = threadIdx.x >> 4;
-    const int64_t base = (int64_t)blockIdx.x * 64 + 4 * l16;
+    __shared__ float4 part[RED_SLICES][RED_LANES];
+    const int l16 = threadIdx.x % RED_LANES, slice = threadIdx.x / RED_LANES;
+    const int base = blockIdx.x * (4 * RED_LANES) + 4 * l16;
+    // prefetch (result unused): row r of the next minibatch, 16 B per thread, strided over the grid
+    if (next_n > 0) {
+        const int rp4 = p.RP >> 2;
+        const int64_t total = (int64_t)next_n * rp4;
+        float keep = 0.0f;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+            const int r = (int)(e / rp4), c4 = (int)(e - (int64_t)r * rp4);
+            int64_t pix = next_perm[r];
+            pix = pix < 0 ? 0 : (pix >= npix ? npix - 1 : pix);
+            const float4 t = *reinterpret_cast<const float4*>(rows + (size_t)pix * p.RP + 4 * c4);
+            keep += t.x;
+        }
+        asm volatile("" ::"v"(keep));
+    }
     const int per = (nwg + RED_SLICES - 1) / RED_SLICES;
     const int w0 = slice * per, w1 = min(nwg, w0 + per);
+    // slice 0 owns the update of its four parameters: fetch their state while the slab reads fly
+    int64_t pidx[4];
+    float pm[4], pv[4], pp[4];
+    if (slice == 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pidx[u] = slab_to_param(base + u, p, F, nl, C);
+            const int64_t j = pidx[u] < 0 ? 0 : pidx[u];
+            pm[u] = m[j]; pv[u] = v[j]; pp[u] = params[j];
+        }
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = slabs + base;
     int w = w0;
     for (; w + 8 <= w1; w += 8) {  // eight loads in flight, added in index order
         float4 t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u) * p.NPP);
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u) * p.slab_floats);
 #pragma unroll
         for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
     }
     for (; w < w1; ++w) {
-        float4 t = *reinterpret_cast<const float4*>(src + (size_t)w * p.NPP);
+        float4 t = *reinterpret_cast<const float4*>(src + (size_t)w * p.slab_floats);
         acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
     part[slice][l16] = acc;
@@ -248,13 +307,13 @@ __global__ void __launch_bounds__(256)
         const float w1c = (float)(1.0 - 0.9), b2 = 0.999f, w2c = (float)(1.0 - 0.999), eps = 1e-8f;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int64_t idx = base + u;
-            if (idx < p.NP) {
+            const int64_t idx = pidx[u];
+            if (idx >= 0) {
                 const float g = gv[u];
-                float mi = m[idx] + w1c * (g - m[idx]);
-                float vi = v[idx] * b2 + w2c * (g * g);
+                float mi = pm[u] + w1c * (g - pm[u]);
+                float vi = pv[u] * b2 + w2c * (g * g);
                 float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
-                float pi = params[idx] + (-step_size) * (mi / denom);
+                float pi = pp[u] + (-step_size) * (mi / denom);
                 m[idx] = mi;
                 v[idx] = vi;
                 params[idx] = pi;
@@ -281,10 +340,10 @@ struct TrainArgs {
     int batch_n;            // rows in this minibatch
     const float* params;    // canonical
     const float* packed;    // fragment order
-    float* slabs;           // [nwg][NPP]
+    float* slabs;           // [nwg][slab_floats]
     double* loss_part;      // [nwg]
     float inv;              // 1 / (batch_n * C)
-    unsigned long long* stamps;  // diagnostic build only (-DLBDRN_TRAIN_STAMPS): [nwg][12] s_memtime
+    unsigned long long* stamps;  // diagnostic build only (-DLBDRN_TRAIN_STAMPS): [nwg][16] s_memtime
 };
 
 #ifdef LBDRN_TRAIN_STAMPS
@@ -300,14 +359,18 @@ struct TrainArgs {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample tile st = 0..1)
+// N contiguous floats (N % 4 == 0) from a 16-byte aligned LDS address into registers
+template <int N>
+__device__ __forceinline__ void lds_load(const float* src, float (&dst)[N])
+{
+#pragma unroll
+    for (int g = 0; g < N / 4; ++g) {
+        float4 v = *reinterpret_cast<const float4*>(src + 4 * g);
+        dst[4 * g] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
+    }
+}
 
-// Two waves share each SIMD.  A wave issues in order, and the ~130 non-MFMA instructions of a tile
-// step (operand reads, address math, accumulator write-out) cannot hide behind its own MFMAs when
-// it is alone on the SIMD (measured: 86 cycles per 32-cycle MFMA in the weight-gradient phase with
-// 4 waves).  With the sample tiles split over two waves per SIMD, one wave's MFMAs cover the
-// other's bookkeeping.
-template <int CH, int NL>
+template <int LQ, int NL>
 __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -315,18 +378,23 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
     const int w = w8 & 3, st = w8 >> 2;
     const int i = lane & 15, q = lane >> 4;
-    const int C = A.net.C, F = A.net.F, FP = p.FP;
+    const int C = A.net.C, F = A.net.F;
+    constexpr int XP = 4 * LQ + 4;
     float* Xs = lds + p.lds_x;
+    float* XT = lds + p.lds_xt;
     float* Hs = lds + p.lds_h;
+    float* HT = lds + p.lds_ht;
     float* Zs = lds + p.lds_z;
+    float* ZT = lds + p.lds_zt;
     float* Zo = lds + p.lds_zo;
-    int* pixs = reinterpret_cast<int*>(lds + p.lds_yx);
+    float* ZoT = lds + p.lds_zot;
+    int* pixs = reinterpret_cast<int*>(lds + p.lds_pix);
     double* red = reinterpret_cast<double*>(lds + p.lds_red);
-    float* Gs = lds + p.lds_g;
     const int wg = blockIdx.x;
     const int first = wg * TB;
     const int nvalid = min(TB, A.batch_n - first);
     const int srow = i + 16 * st;  // the sample (row of X / H / dZ) this lane's B operands come from
+    float* slab = A.slabs + (size_t)wg * p.slab_floats;
 #ifdef LBDRN_TRAIN_STAMPS
     unsigned long long stamp[16] = {};
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[12])::"memory");
@@ -339,10 +407,12 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     if (tid < TB) mypix = A.perm[first + min(tid, nvalid - 1)];
 
     // ---- weight prefetch: everything this wave will multiply by, L2 -> VGPR, before the gather
-    const float* wf0 = A.packed + p.pk_w0 + (size_t)w * p.S0 * 64 + lane;
-    float a0[2][CH];
+    float a0[LQ];
+    {
+        const float* wf0 = A.packed + p.pk_w0 + (size_t)w * LQ * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < CH; ++u) a0[0][u] = wf0[u * 64];
+        for (int s = 0; s < LQ; ++s) a0[s] = wf0[s * 64];
+    }
     float ah[NL > 1 ? NL - 1 : 1][16];
 #pragma unroll
     for (int l = 1; l < NL; ++l)
@@ -351,17 +421,17 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     float al[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) al[s] = A.packed[p.pk_wl + s * 64 + lane];
-    float atl[4];  // W_last^T: A[i = hidden 16w+i][k = channel 4s+q]
+    float atl[4];  // W_last^T: A[i = hidden 16w+i][k = channel 4q+s]
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        int ch = 4 * s + q;
+        int ch = 4 * q + s;
         atl[s] = ch < C ? A.params[p.offW[NL] + (int64_t)ch * TBC + 16 * w + i] : 0.0f;
     }
-    float ath[NL > 1 ? NL - 1 : 1][16];  // W_l^T: A[i = in 16w+i][k = out 4s+q]
+    float ath[NL > 1 ? NL - 1 : 1][16];  // W_l^T: A[i = in 16w+i][k = out 16q+s]
 #pragma unroll
     for (int l = 1; l < NL; ++l)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) ath[l - 1][s] = A.params[p.offW[l] + (int64_t)(4 * s + q) * TBC + 16 * w + i];
+        for (int s = 0; s < 16; ++s) ath[l - 1][s] = A.params[p.offW[l] + (int64_t)(16 * q + s) * TBC + 16 * w + i];
     f32x4 bias[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
@@ -379,67 +449,52 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     }
     __syncthreads();
     STAMP(1);
-    // ---- phase 1: copy the 32 rows (features | labels) into LDS: 16 threads per row, 16 B per load,
-    //      all loads of a batch issued before the first store (a4: ref LBDRNdataset.py:151-155)
+    // ---- phase 1: copy the 32 rows (features | labels) into LDS, row-major (X) and transposed (XT):
+    //      16 threads per row, 16 B per load, all loads issued before the first store
+    //      (a4: ref LBDRNdataset.py:151-155)
     {
         const int s = tid >> 4, sub = tid & 15;
         const float* src = A.rows + (size_t)pixs[s] * p.RP;
-        float* xr = Xs + s * FP;
-        const int rp4 = p.RP >> 2;
-        for (int c0 = 0; c0 < rp4; c0 += 64) {
-            float4 v[4];
+        float* xr = Xs + s * XP;
+        const int rp4 = p.RP >> 2, nt16 = 16 * p.NT0;
+        constexpr int NLD = (XP / 4 + 15) / 16;
+        float4 v[NLD];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int c4 = min(c0 + sub + 16 * u, rp4 - 1);  // clamped: never a load behind a branch
-                v[u] = *reinterpret_cast<const float4*>(src + 4 * c4);
-            }
+        for (int u = 0; u < NLD; ++u) {
+            int c4 = min(sub + 16 * u, rp4 - 1);  // clamped: never a load behind a branch
+            v[u] = *reinterpret_cast<const float4*>(src + 4 * c4);
+        }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int c4 = c0 + sub + 16 * u;
-                if (c4 < rp4) {
-                    *reinterpret_cast<float2*>(xr + 4 * c4) = make_float2(v[u].x, v[u].y);
-                    *reinterpret_cast<float2*>(xr + 4 * c4 + 2) = make_float2(v[u].z, v[u].w);
-                }
+        for (int u = 0; u < NLD; ++u) {
+            const int c4 = sub + 16 * u;
+            if (c4 < rp4) {
+                *reinterpret_cast<float4*>(xr + 4 * c4) = v[u];
+                const float e4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * c4 + e < nt16) XT[(4 * c4 + e) * TP + s] = e4[e];
             }
         }
-        for (int f = p.RP + sub; f < FP; f += 16) xr[f] = 0.0f;  // pad columns read by MFMA steps
+        for (int f = p.RP + sub; f < XP; f += 16) xr[f] = 0.0f;          // pad columns read by MFMA steps
+        for (int f = p.RP + sub; f < nt16; f += 16) XT[f * TP + s] = 0.0f;  // pad rows of the transposed copy
     }
     __syncthreads();
     STAMP(2);
 
-    // ---- phase 2: layer 0, z^T[16w..][16 samples of tile st] = b + W0 X^T
+    // ---- phase 2: layer 0, z^T[16w..][16 samples of tile st] = b + W0 X^T, quarter q walks
+    //      features q*LQ .. q*LQ+LQ-1
     f32x4 acc = bias[0];
-    const float* xb = Xs + srow * FP + q;  // B operand: X[sample][4s + q]
-    const int nch = p.S0 / CH;
-    for (int c = 0; c < nch; c += 2) {
-        if (c + 1 < nch) {
+    {
+        float bx[LQ];
+        lds_load<LQ>(Xs + srow * XP + q * LQ, bx);
 #pragma unroll
-            for (int u = 0; u < CH; ++u) a0[1][u] = wf0[((c + 1) * CH + u) * 64];
-        }
-        {
-            float bx[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) bx[u] = xb[4 * (c * CH + u)];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) acc = MFMA16(a0[0][u], bx[u], acc);
-        }
-        if (c + 1 < nch) {
-            if (c + 2 < nch) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) a0[0][u] = wf0[((c + 2) * CH + u) * 64];
-            }
-            float bx[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) bx[u] = xb[4 * ((c + 1) * CH + u)];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) acc = MFMA16(a0[1][u], bx[u], acc);
-        }
+        for (int s = 0; s < LQ; ++s) acc = MFMA16(a0[s], bx[s], acc);
     }
     STAMP(3);
     // activation; keep cos(30 z) in registers for the backward pass
     f32x4 cs[NL];
     auto activate_store = [&](int l) {
-        f32x4 hv;
+        float hv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float sn, co;
@@ -447,22 +502,21 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
             hv[r] = sn;
             cs[l][r] = co;
         }
-        float* dst = Hs + (size_t)l * TB * HPITCH + srow * HPITCH + 16 * w + 4 * q;
-        *reinterpret_cast<float2*>(dst) = make_float2(hv[0], hv[1]);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(hv[2], hv[3]);
+        *reinterpret_cast<float4*>(Hs + (size_t)l * TB * HP + srow * HP + 16 * w + 4 * q) =
+            make_float4(hv[0], hv[1], hv[2], hv[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) HT[(size_t)l * TBC * TP + (16 * w + 4 * q + r) * TP + srow] = hv[r];
     };
     activate_store(0);
     __syncthreads();
     STAMP(4);
 
-    // ---- phase 3: hidden layers 1..NL-1
+    // ---- phase 3: hidden layers 1..NL-1 (quarter q walks inputs 16q..16q+15)
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
         acc = bias[l];
-        const float* hb = Hs + (size_t)(l - 1) * TB * HPITCH + srow * HPITCH + q;
         float bh[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) bh[s] = hb[4 * s];
+        lds_load<16>(Hs + (size_t)(l - 1) * TB * HP + srow * HP + 16 * q, bh);
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc = MFMA16(ah[l - 1][s], bh[s], acc);
         activate_store(l);
@@ -474,17 +528,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     double lsum = 0.0;
     if (w == 0) {
         f32x4 oe = bias_last, oo = {0.f, 0.f, 0.f, 0.f};
-        const float* hb = Hs + (size_t)(NL - 1) * TB * HPITCH + srow * HPITCH + q;
         float bo[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) bo[s] = hb[4 * s];
+        lds_load<16>(Hs + (size_t)(NL - 1) * TB * HP + srow * HP + 16 * q, bo);
 #pragma unroll
         for (int s = 0; s < 16; s += 2) {
             oe = MFMA16(al[s], bo[s], oe);
             oo = MFMA16(al[s + 1], bo[s + 1], oo);
         }
         const bool live = srow < nvalid;
-        const float* labrow = Xs + srow * FP + F + 4 * q;  // labels ride behind the features
+        const float* labrow = Xs + srow * XP + F + 4 * q;  // labels ride behind the features
         float dzo[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -494,9 +546,9 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
             lsum += ok ? (double)(d * d) : 0.0;                           // ref LBDRNloss.py:9
             dzo[r] = ok ? ((2.0f * d) * A.inv) * (y * (1.0f - y)) : 0.0f;  // mse + sigmoid backward
         }
-        float* dst = Zo + srow * OPITCH + 4 * q;
-        *reinterpret_cast<float2*>(dst) = make_float2(dzo[0], dzo[1]);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(dzo[2], dzo[3]);
+        *reinterpret_cast<float4*>(Zo + srow * OP + 4 * q) = make_float4(dzo[0], dzo[1], dzo[2], dzo[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ZoT[(4 * q + r) * TP + srow] = dzo[r];
         for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o);
         if (lane == 0) red[st] = lsum;
     }
@@ -505,36 +557,33 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     STAMP(6);
 
     auto backprop_store = [&](int l) {  // acc = dL/dh_l  ->  dz_l = (dh * cos(30 z)) * 30
-        f32x4 dz;
+        float dz[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) dz[r] = (acc[r] * cs[l][r]) * 30.0f;
-        float* dst = Zs + (size_t)l * TB * HPITCH + srow * HPITCH + 16 * w + 4 * q;
-        *reinterpret_cast<float2*>(dst) = make_float2(dz[0], dz[1]);
-        *reinterpret_cast<float2*>(dst + 2) = make_float2(dz[2], dz[3]);
+        *reinterpret_cast<float4*>(Zs + (size_t)l * TB * HP + srow * HP + 16 * w + 4 * q) =
+            make_float4(dz[0], dz[1], dz[2], dz[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ZT[(size_t)l * TBC * TP + (16 * w + 4 * q + r) * TP + srow] = dz[r];
     };
 
-    // ---- phase 5: dh_{NL-1} = W_last^T dz_out  (K = 16 channel slots)
+    // ---- phase 5: dh_{NL-1} = W_last^T dz_out  (K = 16 channel slots, quarter q walks 4q..4q+3)
     {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         acc = zero;
-        const float* zb = Zo + srow * OPITCH + q;
         float bz[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) bz[s] = zb[4 * s];
+        lds_load<4>(Zo + srow * OP + 4 * q, bz);
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = MFMA16(atl[s], bz[s], acc);
         backprop_store(NL - 1);
     }
     __syncthreads();
-    // ---- phase 6: dh_{l-1} = W_l^T dz_l
+    // ---- phase 6: dh_{l-1} = W_l^T dz_l  (quarter q walks outputs 16q..16q+15)
 #pragma unroll
     for (int l = NL - 1; l >= 1; --l) {
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         acc = zero;
-        const float* zb = Zs + (size_t)l * TB * HPITCH + srow * HPITCH + q;
         float bz[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) bz[s] = zb[4 * s];
+        lds_load<16>(Zs + (size_t)l * TB * HP + srow * HP + 16 * q, bz);
 #pragma unroll
         for (int s = 0; s < 16; ++s) acc = MFMA16(ath[l - 1][s], bz[s], acc);
         backprop_store(l - 1);
@@ -542,55 +591,41 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     }
     STAMP(7);
 
-    // ---- phase 7: weight gradients, K = 32 samples (8 MFMA steps), assembled in LDS (Gs) in
-    //      parameter order.  dW_l[row0 + row][col] = sum_s dz_l[s][row0 + row] * in_l[s][col];
-    //      this wave takes the 16-column tiles nt = tile0, tile0 + tstep, ...
-    auto grad_tiles = [&](const float* zsrc, int zpitch, const float* bsrc, int bpitch, int ntiles,
-                          int tile0, int tstep, int ncols, int64_t off, int ld, int row0) {
+    // ---- phase 7: weight gradients, K = 32 samples (8 MFMA steps, quarter q walks samples 8q..8q+7):
+    //      dW[16w + row][16nt + col] = sum_s dz[s][16w + row] * in[s][16nt + col]; wave (w, st) takes the
+    //      column tiles nt = st, st+2, ...; each finished tile leaves as one 1 KB store in tile order.
+    auto grad_tiles = [&](const float* zt, const float* bt, int ntiles, float* out) {
         float az[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) az[s] = zsrc[(4 * s + q) * zpitch + row0 + i];
-        // two tiles per trip (two independent accumulator chains); tiles past the end recompute the
-        // last one and are not stored
-        for (int nt = tile0; nt < ntiles; nt += 2 * tstep) {
-            const int nt1 = nt + tstep;
+        lds_load<8>(zt + (16 * w + i) * TP + 8 * q, az);
+        for (int nt = st; nt < ntiles; nt += 4) {
+            const int nt1 = nt + 2;
             const bool two = nt1 < ntiles;
-            const float* b0 = bsrc + q * bpitch + 16 * nt + i;
-            const float* b1 = bsrc + q * bpitch + 16 * (two ? nt1 : nt) + i;
-            float bv[16];
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { bv[s] = b0[4 * s * bpitch]; bv[8 + s] = b1[4 * s * bpitch]; }
+            float b0[8], b1[8];
+            lds_load<8>(bt + (16 * nt + i) * TP + 8 * q, b0);
+            lds_load<8>(bt + (16 * (two ? nt1 : nt) + i) * TP + 8 * q, b1);
             const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
             f32x4 g0 = zero, g1 = zero;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                g0 = MFMA16(az[s], bv[s], g0);
-                g1 = MFMA16(az[s], bv[8 + s], g1);
+                g0 = MFMA16(az[s], b0[s], g0);
+                g1 = MFMA16(az[s], b1[s], g1);
             }
-            float* dst0 = Gs + off + (int64_t)(row0 + 4 * q) * ld + 16 * nt + i;
-            float* dst1 = Gs + off + (int64_t)(row0 + 4 * q) * ld + 16 * nt1 + i;
-            const bool ok0 = 16 * nt + i < ncols, ok1 = two && 16 * nt1 + i < ncols;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (ok0) dst0[r * ld] = g0[r];
-                if (ok1) dst1[r * ld] = g1[r];
-            }
+            *reinterpret_cast<float4*>(out + ((size_t)(w * ntiles + nt) * 64 + lane) * 4) =
+                make_float4(g0[0], g0[1], g0[2], g0[3]);
+            if (two)
+                *reinterpret_cast<float4*>(out + ((size_t)(w * ntiles + nt1) * 64 + lane) * 4) =
+                    make_float4(g1[0], g1[1], g1[2], g1[3]);
         }
     };
-    grad_tiles(Zs, HPITCH, Xs, FP, p.NT0, st, 2, F, p.offW[0], F, 16 * w);
+    grad_tiles(ZT, XT, p.NT0, slab);
     STAMP(10);
 #pragma unroll
     for (int l = 1; l < NL; ++l)
-        grad_tiles(Zs + (size_t)l * TB * HPITCH, HPITCH, Hs + (size_t)(l - 1) * TB * HPITCH, HPITCH, 4, st, 2,
-                   TBC, p.offW[l], TBC, 16 * w);
-    if (st == 0) {  // output layer: rows = channels, wave w takes hidden columns 16w..16w+15
-        float az[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) az[s] = Zo[(4 * s + q) * OPITCH + i];
-        const float* b0 = Hs + (size_t)(NL - 1) * TB * HPITCH + q * HPITCH + 16 * w + i;
-        float bv[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) bv[s] = b0[4 * s * HPITCH];
+        grad_tiles(ZT + (size_t)l * TBC * TP, HT + (size_t)(l - 1) * TBC * TP, 4, slab + p.sl_hid + (l - 1) * 16 * 256);
+    if (st == 0) {  // output layer: rows = channel slots, wave w takes hidden columns 16w..16w+15
+        float az[8], bv[8];
+        lds_load<8>(ZoT + i * TP + 8 * q, az);
+        lds_load<8>(HT + (size_t)(NL - 1) * TBC * TP + (16 * w + i) * TP + 8 * q, bv);
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 g0 = zero, g1 = zero;
 #pragma unroll
@@ -598,40 +633,21 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
             g0 = MFMA16(az[s], bv[s], g0);
             g1 = MFMA16(az[s + 1], bv[s + 1], g1);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ch = 4 * q + r;
-            if (ch < C) Gs[p.offW[NL] + (int64_t)ch * TBC + 16 * w + i] = g0[r] + g1[r];
-        }
+        *reinterpret_cast<float4*>(slab + p.sl_out + ((size_t)w * 64 + lane) * 4) =
+            make_float4(g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]);
     }
     STAMP(11);
-    // bias gradients: column sums over the 32 samples, one thread per unit, samples in order
-    for (int u = tid; u < NL * TBC + C; u += TRAIN_THREADS) {
+    // bias gradients: sums over the 32 samples of one unit = one row of the transposed copies
+    for (int u = tid; u < NL * TBC + 16; u += TRAIN_THREADS) {
+        float zz[TB];
+        lds_load<TB>(u < NL * TBC ? ZT + (size_t)u * TP : ZoT + (size_t)(u - NL * TBC) * TP, zz);
         float v = 0.0f;
-        if (u < NL * TBC) {
-            const int l = u >> 6, n = u & 63;
-            const float* z = Zs + (size_t)l * TB * HPITCH + n;
-            float zz[TB];
 #pragma unroll
-            for (int s = 0; s < TB; ++s) zz[s] = z[s * HPITCH];
-#pragma unroll
-            for (int s = 0; s < TB; ++s) v += zz[s];
-            Gs[p.offB[l] + n] = v;
-        } else {
-            const int ch = u - NL * TBC;
-            for (int s = 0; s < TB; ++s) v += Zo[s * OPITCH + ch];
-            Gs[p.offB[NL] + ch] = v;
-        }
+        for (int s = 0; s < TB; ++s) v += zz[s];
+        slab[p.sl_bias + u] = v;
     }
-    for (int u = (int)p.NP + tid; u < p.NPP; u += TRAIN_THREADS) Gs[u] = 0.0f;
-    __syncthreads();
+    for (int u = p.sl_bias + NL * TBC + 16 + tid; u < p.slab_floats; u += TRAIN_THREADS) slab[u] = 0.0f;
     STAMP(8);
-    // ---- phase 8: the slab leaves as full-width stores (16 B per lane, 1 KB per wave instruction)
-    {
-        float4* dst = reinterpret_cast<float4*>(A.slabs + (size_t)wg * p.NPP);
-        const float4* srcg = reinterpret_cast<const float4*>(Gs);
-        for (int u = tid; u < (p.NPP >> 2); u += TRAIN_THREADS) dst[u] = srcg[u];
-    }
 #ifdef LBDRN_TRAIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(9);
@@ -643,10 +659,10 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 
 // ------------------------------------------------------------------ host driver
 
-template <int CH, int NL>
+template <int LQ, int NL>
 static int launch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
-    auto kern = k_train_mfma<CH, NL>;
+    auto kern = k_train_mfma<LQ, NL>;
     const size_t lds_bytes = (size_t)A.p.lds_floats * 4;
     static thread_local size_t configured = 0;
     if (configured < lds_bytes) {
@@ -659,17 +675,22 @@ static int launch_train(const TrainArgs& A, int nwg, hipStream_t s)
     return 0;
 }
 
+template <int LQ>
+static int dispatch_nl(const TrainArgs& A, int nwg, hipStream_t s)
+{
+    if (A.net.nl == 1) return launch_train<LQ, 1>(A, nwg, s);
+    if (A.net.nl == 2) return launch_train<LQ, 2>(A, nwg, s);
+    return launch_train<LQ, 3>(A, nwg, s);
+}
+
 static int dispatch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
-    const int nl = A.net.nl, ch = A.p.CH;
-    if (ch == 10) {
-        if (nl == 1) return launch_train<10, 1>(A, nwg, s);
-        if (nl == 2) return launch_train<10, 2>(A, nwg, s);
-        return launch_train<10, 3>(A, nwg, s);
+    switch (A.p.LQ) {
+        case 16: return dispatch_nl<16>(A, nwg, s);
+        case 32: return dispatch_nl<32>(A, nwg, s);
+        case 52: return dispatch_nl<52>(A, nwg, s);
+        default: return dispatch_nl<64>(A, nwg, s);
     }
-    if (nl == 1) return launch_train<8, 1>(A, nwg, s);
-    if (nl == 2) return launch_train<8, 2>(A, nwg, s);
-    return launch_train<8, 3>(A, nwg, s);
 }
 
 // Build the per-image state of the fused training path in the caller's workspace: the
@@ -735,9 +756,10 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
         if (int rc = dispatch_train(A, nwg, s)) return rc;
         ++step;
         const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
-        k_reduce_adam<<<(unsigned)(A.p.NPP / 64), 256, 0, s>>>(
+        k_reduce_adam<<<(unsigned)(A.p.slab_floats / (4 * RED_LANES)), 256, 0, s>>>(
             slabs, nwg, A.p, net.F, net.nl, net.C, params, m, v, packed, (float)(lr / bc1),
-            (float)std::sqrt(bc2), loss_part, (double)B * net.C, losses ? losses + si : nullptr);
+            (float)std::sqrt(bc2), loss_part, (double)B * net.C, losses ? losses + si : nullptr,
+            perm + first, 0 /* next-batch prefetch: measured slower (+2.9 us in this kernel, -0.6 us in the next) */, rows, A.npix);
         LBDRN_LAUNCH_CHECK();
     }
 #ifdef LBDRN_TRAIN_STAMPS
@@ -746,22 +768,19 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
         std::vector<unsigned long long> h((size_t)max_wg * 16);
         LBDRN_HIP_TRY(hipMemcpy(h.data(), A.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         (void)hipFree(A.stamps);
-        double sum[12] = {};
-        for (int wq = 0; wq < max_wg; ++wq)
-            for (int k = 1; k < 10; ++k) sum[k] += (double)(h[wq * 16 + k] - h[wq * 16 + k - 1]);
-        double d10 = 0, d11 = 0, d8 = 0, clk = 0;
+        double sum[12] = {}, d10 = 0, d11 = 0, d8 = 0, clk = 0;
         for (int wq = 0; wq < max_wg; ++wq) {
+            for (int k = 1; k < 10; ++k)
+                if (k != 8) sum[k] += (double)(h[wq * 16 + k] - h[wq * 16 + (k == 9 ? 8 : k - 1)]);
             d10 += (double)(h[wq * 16 + 10] - h[wq * 16 + 7]);
             d11 += (double)(h[wq * 16 + 11] - h[wq * 16 + 10]);
             d8 += (double)(h[wq * 16 + 8] - h[wq * 16 + 11]);
             clk += (double)(h[wq * 16 + 9] - h[wq * 16 + 0]) / (double)(h[wq * 16 + 13] - h[wq * 16 + 12]) * 100.0;
         }
-        fprintf(stderr, "[lbdrn stamps] mean in-kernel clock %.0f MHz\n", clk / max_wg);
-        fprintf(stderr, "[lbdrn stamps] dW0 %.0f dWhid+out %.0f bias+pad+barrier %.0f\n", d10 / max_wg, d11 / max_wg, d8 / max_wg);
-        fprintf(stderr, "[lbdrn stamps] mean cycles/phase: perm %.0f rows %.0f L0mfma %.0f act0 %.0f hidden %.0f "
-                        "out+loss %.0f backprop %.0f dW->LDS %.0f slab-out %.0f\n",
-                sum[1] / max_wg, sum[2] / max_wg, sum[3] / max_wg, sum[4] / max_wg, sum[5] / max_wg,
-                sum[6] / max_wg, sum[7] / max_wg, sum[8] / max_wg, sum[9] / max_wg);
+        fprintf(stderr, "[lbdrn stamps] in-kernel clock %.0f MHz; mean cycles/phase: perm %.0f rows %.0f L0 %.0f act0 %.0f "
+                        "hidden %.0f out+loss %.0f backprop %.0f dW0 %.0f dWhid+out %.0f bias %.0f drain %.0f\n",
+                clk / max_wg, sum[1] / max_wg, sum[2] / max_wg, sum[3] / max_wg, sum[4] / max_wg, sum[5] / max_wg,
+                sum[6] / max_wg, sum[7] / max_wg, d10 / max_wg, d11 / max_wg, d8 / max_wg, sum[9] / max_wg);
     }
 #endif
     return 0;

@@ -1,0 +1,216 @@
+"""The fused MFMA training step against the generic kernels and the oracle over the shapes it
+supports, end-to-end encode/decode through the CLIs, and full-size properties."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from lbdrn_hip import codec, container, ops, raster_io
+from lbdrn_hip.features import FeatCfg
+from lbdrn_hip.synth import synthetic_tile
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GEN, MFMA = ops._lib.PATH_GENERIC, ops._lib.PATH_MFMA
+
+
+def _params(rng, F, bc, C, nl):
+    parts = []
+    for l in range(nl):
+        nin = F if l == 0 else bc
+        b = 1.0 / nin if l == 0 else np.sqrt(6.0 / nin) / 30.0
+        parts += [rng.uniform(-b, b, bc * nin), rng.uniform(-b, b, bc)]
+    b = np.sqrt(6.0 / bc) / 30.0
+    parts += [rng.uniform(-b, b, C * bc), rng.uniform(-b, b, C)]
+    return np.concatenate(parts).astype(np.float32)
+
+
+CASES = [
+    # C, H, W, K, D, nl, bs, flags(coords, embed, colors, relative)
+    (8, 40, 52, 5, 2, 2, 512, (0, 0, 1, 1)),      # F=200, LQ=52: the north-star shape, short last batch
+    (4, 30, 41, 5, 2, 1, 300, (0, 0, 1, 1)),      # F=100 (LQ=32), one hidden layer, ragged workgroups
+    (3, 25, 33, 3, 1, 3, 256, (0, 0, 1, 1)),      # F=27 (LQ=16), three hidden layers
+    (16, 20, 24, 6, 0, 2, 128, (0, 0, 1, 1)),     # D=0: F=C=16, all 16 output slots used
+    (8, 24, 36, 5, 2, 2, 400, (1, 1, 1, 1)),      # F=250 (LQ=64): positional embedding, config 5
+    (1, 31, 29, 4, 3, 2, 200, (1, 0, 1, 0)),      # one band, coords without embedding, absolute colours
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_mfma_epoch_matches_generic_and_oracle(dev, case):
+    C, H, W, K, D, nl, bs, flags = case
+    rng = np.random.default_rng(sum(case[:7]))
+    cfg = FeatCfg(bool(flags[0]), bool(flags[1]), 1.4, 12, bool(flags[2]), bool(flags[3]))
+    ocfg = O.FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative)
+    img = synthetic_tile(int(rng.integers(100)), C, H, W)
+    msb, lab, mx = O.split_bits(img, K)
+    F = cfg.feature_dim(C, D)
+    p0 = _params(rng, F, 64, C, nl)
+    perm_np = rng.permutation(H * W).astype(np.int64)
+    perm = torch.from_numpy(perm_np).to(dev)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+    net = ops.make_net(F, 64, C, nl)
+    img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+    nsteps = (H * W + bs - 1) // bs
+    res = {}
+    for path in (GEN, MFMA):
+        p = torch.from_numpy(p0.copy()).to(dev)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        losses = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+        ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 3, 1e-3, losses, path=path)
+        res[path] = (p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), losses.cpu().numpy())
+    # oracle, step by step
+    feats = O.features(msb, D, ocfg, mx)
+    po, mo, vo = p0.copy(), np.zeros_like(p0), np.zeros_like(p0)
+    lo = []
+    for s in range(nsteps):
+        b = perm_np[s * bs:(s + 1) * bs]
+        l, _ = O.train_step(po, mo, vo, F, 64, C, nl, feats[b], lab[b], 1e-3, 3 + s + 1)
+        lo.append(l)
+    for path in (GEN, MFMA):
+        p, m, v, losses = res[path]
+        np.testing.assert_allclose(losses, np.array(lo), rtol=1e-5), path   # north_star tolerance
+        assert np.linalg.norm(p - po) <= 2e-5 * np.linalg.norm(po), path
+        assert np.abs(m - mo).max() <= 2e-5 * np.abs(mo).max(), path
+        assert np.abs(v - vo).max() <= 5e-5 * np.abs(vo).max(), path
+
+
+def test_mfma_train_rejects_unsupported_shapes(dev):
+    img = synthetic_tile(1, 4, 16, 16)
+    msb, _, mx = O.split_bits(img, 5)
+    geom = ops.FeatureGeometry(4, 16, 16, 5, 2, mx, FeatCfg(), dev)
+    net = ops.make_net(100, 128, 4, 2)   # bc=128: generic only
+    ws = ops.TrainWorkspace(geom, net, 64, dev)
+    with pytest.raises(ops._lib.LbdrnError):
+        ws.prepare(ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev), MFMA)
+    # the generic path takes it
+    p = torch.from_numpy(_params(np.random.default_rng(0), 100, 128, 4, 2)).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    perm = torch.randperm(256, device=dev)
+    ops.train_epoch(geom, net, ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev), perm, 64, p, m, v, 0, 1e-3)
+    assert torch.isfinite(p).all()
+
+
+def test_fit_is_independent_of_path_choice_and_reproducible(dev):
+    """Whole fit (3 epochs, eval + best-epoch selection) twice on the default path: identical bits;
+    the generic path lands within training tolerance and picks the same best epoch."""
+    img = synthetic_tile(5, 8, 48, 64)
+    outs = []
+    for path in (ops._lib.PATH_AUTO, ops._lib.PATH_AUTO, GEN):
+        torch.manual_seed(19920517)
+        fit = codec.fit_device(ops.to_device_u16(img, dev), 5, 2, 64, 2, 1e-3, 512, 3, path=path)
+        outs.append((fit.best_params.cpu().numpy(), fit.mse_log.cpu().numpy()))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.linalg.norm(outs[0][0] - outs[2][0]) <= 1e-4 * np.linalg.norm(outs[2][0])
+    np.testing.assert_allclose(outs[0][1][:, 0], outs[2][1][:, 0], rtol=1e-5)
+    assert np.array_equal(outs[0][1][:, 1], outs[2][1][:, 1])
+
+
+def test_fit_matches_torch_port_trajectory(dev):
+    """Same seed, same draws: the first epochs of the HIP fit follow the torch-CPU restatement of the
+    reference loop (loss per step within 1e-4 while the trajectories have not yet drifted)."""
+    import torch_port as TP
+    img = synthetic_tile(2, 8, 32, 48)
+    torch.manual_seed(19920517)
+    r = TP.fit(img, 5, 2, 64, 2, 1e-3, 256, 2, faithful=False)
+    torch.manual_seed(19920517)
+    fit = codec.fit_device(ops.to_device_u16(img, dev), 5, 2, 64, 2, 1e-3, 256, 2, keep_losses=True)
+    l_hip = fit.losses.cpu().numpy().reshape(-1)
+    np.testing.assert_allclose(l_hip, np.array(r["losses"]), rtol=1e-4)
+    mse = fit.mse_log.cpu().numpy()
+    for (e, m_ref, imp), row in zip(r["epoch_mse"], mse):
+        assert abs(row[0] - m_ref) <= 1e-4 * m_ref and bool(row[1]) == imp
+
+
+def test_cli_round_trip(dev, tmp_path):
+    """encode.py -> .bin -> decode.py on a small TIFF: container layout, log records the reference's
+    results_summary.py regexes expect, high bits preserved, and the decoded raster equals the oracle's
+    decode of the very payload the file carries."""
+    import re
+    img = synthetic_tile(11, 8, 40, 56)
+    src = tmp_path / "tile.tif"
+    raster_io.write_raster(str(src), img)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"))
+    enc = [sys.executable, os.path.join(ROOT, "lbdrn-msic_amd", "encode.py"), "-i", str(src), "-o", str(tmp_path / "out"),
+           "-K", "5", "-D", "2", "-bc", "64", "-nl", "2", "-lr", "0.001", "-bs", "512", "-e", "3", "-sr", "1", "-prec", "16"]
+    subprocess.run(enc, check=True, env=env, capture_output=True)
+    outdir = tmp_path / "out" / "tile_r1_K5_bc64_nl2_D2_prec16_lr0.001_bs512_e3"
+    binp = outdir / "tile.bin"
+    raw = binp.read_bytes()
+    n, sr, w, h, K, bc, nl, D, nn, base = container.unpack_header(raw)
+    assert (n, sr, w, h, K, bc, nl, D) == (15, 1, 56, 40, 5, 64, 2, 2)
+    assert n + nn[0] + base[0] == len(raw)
+    log = (outdir / "encode.txt").read_text()
+    assert re.search(r"nn: (\d+) bytes", log) and re.search(r"MSB: (\d+) bytes", log)
+    assert re.search(r"Time elapsed: (\d+\.\d+)", log) and "best epoch" in log
+    # decode with -org: metrics logged, recon removed (ref decode.py:223-224)
+    dec = [sys.executable, os.path.join(ROOT, "lbdrn-msic_amd", "decode.py"), "-i", str(binp), "-org", str(src)]
+    subprocess.run(dec, check=True, env=env, capture_output=True)
+    dlog = (outdir / "decode.txt").read_text()
+    mse = float(re.search(r"MSE: (\d+\.\d+)", dlog).group(1))
+    psnr = float(re.search(r"PSNR: (\d+\.\d+)", dlog).group(1))
+    assert re.search(r"bpsp=(\d+\.\d+)", dlog) and re.search(r"Total size: (\d+) bytes", dlog)
+    assert not (outdir / "tile_recon.tif").exists()
+    assert abs(psnr - 10 * np.log10(1e8 / mse)) < 1e-3 and psnr > 55
+    # decoded raster == oracle decode of the payload in the file
+    params = container.decode_weights(raw[n:n + nn[0]])
+    msb = container.decode_base(raw[n + nn[0]:])
+    assert np.array_equal(msb, img >> 5)
+    rec_o = O.decode(msb.astype(np.uint16), 5, 2, O.FeatCfg(), params, 64, 2)
+    rec = codec.apply_image(msb, params, 5, 2, 64, 2, cfg=FeatCfg())
+    assert np.array_equal(rec, rec_o)
+    assert abs(float(np.mean((img.astype(np.float32) - rec.astype(np.float32)) ** 2)) - mse) < 1e-3 * mse
+    # second invocation: both CLIs see their completion markers and skip
+    assert "already" in subprocess.run(enc, check=True, env=env, capture_output=True, text=True).stdout
+    assert "already" in subprocess.run(dec, check=True, env=env, capture_output=True, text=True).stdout
+
+
+def test_cli_split_ratio_tiles(dev, tmp_path):
+    img = synthetic_tile(12, 4, 33, 47)
+    src = tmp_path / "t.tif"
+    raster_io.write_raster(str(src), img)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"))
+    subprocess.run([sys.executable, os.path.join(ROOT, "lbdrn-msic_amd", "encode.py"), "-i", str(src), "-o",
+                    str(tmp_path / "o"), "-K", "4", "-D", "1", "-bs", "128", "-e", "1", "-sr", "2"],
+                   check=True, env=env, capture_output=True)
+    outdir = tmp_path / "o" / "t_r2_K4_bc64_nl2_D1_prec16_lr0.001_bs128_e1"
+    raw = (outdir / "t.bin").read_bytes()
+    n, sr, w, h, K, bc, nl, D, nn, base = container.unpack_header(raw)
+    assert (n, sr, w, h) == (8 + 7 * 4, 2, 47, 33) and n + sum(nn) + sum(base) == len(raw)
+    import decode as dec_mod
+    sys.argv = ["decode.py"]
+    assert dec_mod.main(["-i", str(outdir / "t.bin")]) == 0
+    rec = raster_io.read_raster(str(outdir / "t_recon.tif"))
+    assert rec.shape == img.shape and np.array_equal(rec >> 4, img >> 4)
+
+
+def test_full_size_properties(dev):
+    """BASELINE.json configs[1] size: the two independent HIP implementations (generic tiled FMA
+    kernels, fused MFMA kernel) agree bit for bit on the 33.5 M decoded sub-pixels, high bits are
+    preserved exactly, the reconstruction error is bounded by the dropped bits, and the whole-image
+    SSE of the two paths agrees to 1e-12."""
+    C, H, W, K, D = 8, 2048, 2048, 5, 2
+    img = synthetic_tile(0, C, H, W)
+    img_d = ops.to_device_u16(img, dev)
+    msb_d, mx = ops.split_bits(img_d, K)
+    assert mx == int((img >> K).max())
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(200, 64, C, 2)
+    p = torch.from_numpy(_params(np.random.default_rng(1), 200, 64, C, 2) * 2.0).to(dev)
+    a = ops.decode_fused(geom, net, msb_d, p, path=MFMA)
+    b = ops.decode_fused(geom, net, msb_d, p, path=GEN)
+    assert torch.equal(a, b)
+    rec = ops.from_device_u16(a)
+    assert np.array_equal(rec >> K, img >> K)
+    assert np.abs(rec.astype(np.int32) - img.astype(np.int32)).max() <= 31
+    s1 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA).item())
+    s2 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item())
+    assert abs(s1 - s2) <= 1e-12 * s2
+    # SSE is consistent with the decoded raster: sum((y - lab)^2) vs residuals, within rounding of y*31
+    lsb_err = ((rec & 31).astype(np.float64) - (img & 31)) / 31.0
+    assert abs(np.sum(lsb_err ** 2) - s1) / s1 < 0.05
