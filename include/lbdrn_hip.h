@@ -129,6 +129,16 @@ int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t 
                       double lr, float *losses, void *workspace, size_t workspace_bytes,
                       int32_t path, void *stream);
 
+/* a4 -- the minibatch order: perm[0..n) = torch.randperm(n, generator=torch.Generator().manual_seed(seed))
+ * of a CPU generator, bit for bit (the call RandomSampler.__iter__ makes for DataLoader(shuffle=True),
+ * torch/utils/data/sampler.py:163-183, behind encode.py:69-70), computed on the GPU.  Supported for
+ * n < 2^32/20 (torch's Fisher-Yates branch); larger n returns LBDRN_E_UNSUPPORTED. */
+size_t lbdrn_randperm_workspace(int64_t n, int32_t count);
+/* count permutations at once (1 <= count <= 32; seeds is a HOST array): perm[c][0..n) for seeds[c].
+ * The MT19937 recurrence is serial, so a fit generates the orders of all its epochs in one call. */
+int lbdrn_randperm(const uint64_t *seeds, int32_t count, int64_t n, int64_t *perm, void *workspace,
+                   size_t workspace_bytes, void *stream);
+
 /* a7/a8 building block exposed for teacher-forced parity tests: one update on an explicit
  * minibatch x[B][F], t[B][C]; grads (optional) receives d(loss)/d(params). */
 int lbdrn_train_step(const lbdrn_net *net, const float *x, const float *t, int32_t B,

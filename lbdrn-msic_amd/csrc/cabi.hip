@@ -14,6 +14,9 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
                      size_t ws_bytes, hipStream_t s);
+size_t randperm_workspace(int64_t n, int count);
+int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, void* ws, size_t ws_bytes,
+                   hipStream_t s);
 }  // namespace lbdrn
 
 using namespace lbdrn;
@@ -222,6 +225,20 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
                                 adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
     return generic_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t lbdrn_randperm_workspace(int64_t n, int32_t count)
+{
+    if (n < 0 || count < 1 || count > 32) return 0;
+    return randperm_workspace(n, count);
+}
+
+int lbdrn_randperm(const uint64_t* seeds, int32_t count, int64_t n, int64_t* perm, void* workspace,
+                   size_t workspace_bytes, void* stream)
+{
+    LBDRN_REQUIRE(n >= 0 && (perm || n == 0), "bad n or null output");
+    NEED_DEVICE();
+    return randperm_batch(seeds, count, n, perm, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int lbdrn_train_step(const lbdrn_net* net, const float* x, const float* t, int32_t B, float* params,

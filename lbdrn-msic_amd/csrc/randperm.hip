@@ -1,0 +1,196 @@
+// torch.randperm(n, generator=Generator().manual_seed(seed)) for CPU generators, bit for bit, on the
+// GPU (a4: the minibatch order of DataLoader(shuffle=True), ref encode.py:69-70 via
+// torch/utils/data/sampler.py:163-183).
+//
+// What torch does on the host (aten TensorFactories.cpp randperm_cpu, n < 2^32/20): r = 0..n-1, then a
+// forward Fisher-Yates pass "for i in 0..n-2: swap(r[i], r[i + mt19937() % (n - i)])" -- 4.19 M
+// dependent swaps with random access, 60-300 ms per epoch on a host core, which made the whole fit
+// host-bound (ten permutations per image against ~200 ms of GPU work).
+//
+// Parallel reformulation (exact): position i is final after step i and holds the value that sat at
+// j_i = i + z_i just before step i.  That value is p itself if no earlier step targeted p, else it is
+// whatever sat at position i' before step i', where i' is the latest step < i with j_i' = p -- a
+// chain that walks to ever earlier steps (one hop on average).  So:
+//   1. one workgroup runs the MT19937 recurrence (three 227-wide phases per 624 words) and emits the
+//      targets j_i;  2. the steps are bucketed by target (count, exclusive scan, scatter);
+//   3. every position chases its chain through the buckets, independently.
+// Bucket order is irrelevant (each hop takes the maximum step below a bound), so the atomics used to
+// fill the buckets do not affect the result.  tests/test_gpu_randperm.py checks equality with
+// torch.randperm for many (seed, n).
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.hpp"
+
+namespace lbdrn {
+
+constexpr int MT_N = 624, MT_M = 397;
+
+__device__ __forceinline__ uint32_t mt_twist(uint32_t u, uint32_t v)
+{
+    uint32_t y = (u & 0x80000000u) | (v & 0x7fffffffu);
+    return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
+}
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y)
+{
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+// j[i] = i + mt19937_output(i) % (n - i) for i < n-1;  j[n-1] = n-1.  One workgroup of 256 threads per
+// permutation (blockIdx.x): the recurrence is serial (5 ms for 4 M words), so the permutations of all
+// epochs of a fit are generated side by side in one launch.
+struct SeedList { uint32_t s[32]; };
+__global__ void __launch_bounds__(256) k_mt19937_targets(SeedList seeds, uint32_t n, uint32_t* __restrict__ jall, size_t jstride)
+{
+    __shared__ uint32_t st[2][MT_N];
+    const int tid = threadIdx.x;
+    const uint32_t seed = seeds.s[blockIdx.x];
+    uint32_t* __restrict__ j = jall + (size_t)blockIdx.x * jstride;
+    if (tid == 0) {  // init_genrand, as at::mt19937(seed)
+        uint32_t x = seed;
+        st[0][0] = x;
+        for (int k = 1; k < MT_N; ++k) {
+            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+            st[0][k] = x;
+        }
+        if (n > 0) j[n - 1] = n - 1;
+    }
+    __syncthreads();
+    const uint32_t steps = n > 0 ? n - 1 : 0;
+    int cur = 0;
+    for (uint32_t base = 0; base < steps; base += MT_N) {
+        const uint32_t* o = st[cur];
+        uint32_t* w = st[cur ^ 1];
+        if (tid < 227) w[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
+        __syncthreads();
+        if (tid < 227) w[tid + 227] = w[tid] ^ mt_twist(o[tid + 227], o[tid + 228]);
+        __syncthreads();
+        if (tid < 169) w[tid + 454] = w[tid + 227] ^ mt_twist(o[tid + 454], o[tid + 455]);
+        if (tid == 169) w[623] = w[396] ^ mt_twist(o[623], w[0]);
+        __syncthreads();
+        for (int k = tid; k < MT_N; k += 256) {
+            const uint32_t i = base + k;
+            if (i < steps) j[i] = i + mt_temper(w[k]) % (n - i);
+        }
+        cur ^= 1;  // the next block reads this one (the barrier above orders the writes before those reads,
+                   // and the outputs read w, which the next block only reads as well)
+    }
+}
+
+__global__ void __launch_bounds__(256) k_count_targets(const uint32_t* __restrict__ j, uint32_t steps, uint32_t* __restrict__ cnt)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < steps) atomicAdd(&cnt[j[i]], 1u);
+}
+
+__global__ void __launch_bounds__(256)
+    k_fill_buckets(const uint32_t* __restrict__ j, uint32_t steps, const uint32_t* __restrict__ off,
+                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < steps) {
+        uint32_t p = j[i];
+        entries[off[p] + atomicAdd(&cursor[p], 1u)] = i;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+    k_chase(const uint32_t* __restrict__ j, uint32_t n, const uint32_t* __restrict__ off,
+            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ entries, int64_t* __restrict__ out)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t p = j[i], t = i;
+    for (;;) {
+        const uint32_t b = off[p], e = b + cnt[p];
+        int64_t best = -1;
+        for (uint32_t k = b; k < e; ++k) {
+            const uint32_t s = entries[k];
+            if (s < t && (int64_t)s > best) best = s;
+        }
+        if (best < 0) break;
+        p = t = (uint32_t)best;
+    }
+    out[i] = p;
+}
+
+struct PermWs {
+    uint32_t *j, *cnt, *off, *cursor, *entries;
+    void* scan_tmp;
+    size_t scan_bytes, arr, total;
+};
+
+static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
+{
+    size_t scan_bytes = 0;
+    uint32_t* nul = nullptr;
+    if (rocprim::exclusive_scan(nullptr, scan_bytes, nul, nul, 0u, (size_t)std::max<int64_t>(n, 1),
+                                rocprim::plus<uint32_t>()) != hipSuccess)
+        return LBDRN_E_DEVICE;
+    const size_t arr = align_up((size_t)std::max<int64_t>(n, 1) * sizeof(uint32_t), 256);
+    char* p = (char*)ws;
+    w->j = (uint32_t*)p; p += arr * count;     // one target array per permutation
+    w->cnt = (uint32_t*)p; p += arr;
+    w->cursor = (uint32_t*)p; p += arr;         // cnt and cursor adjacent: one memset
+    w->off = (uint32_t*)p; p += arr;
+    w->entries = (uint32_t*)p; p += arr;
+    w->scan_tmp = p; p += align_up(scan_bytes, 256);
+    w->scan_bytes = scan_bytes;
+    w->arr = arr;
+    w->total = (size_t)(p - (char*)ws);
+    return 0;
+}
+
+size_t randperm_workspace(int64_t n, int count)
+{
+    PermWs w;
+    if (count < 1 || carve_perm(n, count, nullptr, &w)) return 0;
+    return w.total;
+}
+
+// out[c][0..n) = torch.randperm(n, generator=manual_seed(seeds[c])) for c < count (count <= 32)
+int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, void* ws, size_t ws_bytes,
+                   hipStream_t s)
+{
+    LBDRN_REQUIRE(n >= 0 && count >= 1 && count <= 32 && seeds, "bad n / count (1..32) / seeds");
+    if (n >= (int64_t)(0xffffffffu / 20)) {
+        set_error("n=%lld: torch switches to another algorithm at n >= 2^32/20", (long long)n);
+        return LBDRN_E_UNSUPPORTED;
+    }
+    if (n == 0) return 0;
+    PermWs w;
+    if (int rc = carve_perm(n, count, ws, &w)) return rc;
+    if (!ws || ws_bytes < w.total) {
+        set_error("randperm workspace too small: %zu < %zu", ws_bytes, w.total);
+        return LBDRN_E_WORKSPACE;
+    }
+    const uint32_t un = (uint32_t)n, steps = un - 1;
+    SeedList sl;
+    for (int c = 0; c < 32; ++c) sl.s[c] = c < count ? (uint32_t)(seeds[c] & 0xffffffffu) : 0u;
+    k_mt19937_targets<<<count, 256, 0, s>>>(sl, un, w.j, w.arr / sizeof(uint32_t));
+    LBDRN_LAUNCH_CHECK();
+    for (int c = 0; c < count; ++c) {
+        const uint32_t* j = w.j + (size_t)c * (w.arr / sizeof(uint32_t));
+        LBDRN_HIP_TRY(hipMemsetAsync(w.cnt, 0, 2 * w.arr, s));
+        if (steps) {
+            k_count_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, w.cnt);
+            LBDRN_LAUNCH_CHECK();
+        }
+        LBDRN_HIP_TRY(rocprim::exclusive_scan(w.scan_tmp, w.scan_bytes, w.cnt, w.off, 0u, (size_t)n,
+                                              rocprim::plus<uint32_t>(), s));
+        if (steps) {
+            k_fill_buckets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, w.off, w.cursor, w.entries);
+            LBDRN_LAUNCH_CHECK();
+        }
+        k_chase<<<(un + 255) / 256, 256, 0, s>>>(j, un, w.off, w.cnt, w.entries, out + (size_t)c * n);
+        LBDRN_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+}  // namespace lbdrn

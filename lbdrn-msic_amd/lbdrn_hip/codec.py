@@ -12,7 +12,7 @@ import torch
 from . import ops
 from .features import FeatCfg
 from .model import LBDRNModel
-from .sampler import PermutationStream
+from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, PermutationStream
 
 
 def lr_schedule(lr, epochs):
@@ -78,7 +78,8 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     params = model.flat_parameters().to(dev).contiguous()
     exp_avg = torch.zeros_like(params)
     exp_avg_sq = torch.zeros_like(params)
-    stream = PermutationStream(N, epochs, val_duration, workers=perm_workers)
+    stream = (DevicePermutationStream(N, epochs, val_duration, dev) if N < GPU_RANDPERM_MAX
+              else PermutationStream(N, epochs, val_duration, workers=perm_workers))
     lrs = lr_schedule(lr, epochs)
     steps_per_epoch = (N + batch_size - 1) // batch_size
     losses = torch.zeros((epochs, steps_per_epoch), dtype=torch.float32, device=dev) if keep_losses else None
@@ -89,7 +90,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     mse_log = torch.zeros((epochs, 2), dtype=torch.float32, device=dev)
     adam_steps = 0
     for e in range(1, epochs + 1):
-        perm = stream.get(e).to(dev, non_blocking=True)                  # a4
+        perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
         ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
                         adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
         adam_steps += steps_per_epoch

@@ -200,6 +200,21 @@ def train_step(net, x, t, params, exp_avg, exp_avg_sq, adam_step, lr, apply_adam
     return loss, grads
 
 
+def randperm(seeds, n, device):
+    """[len(seeds), n] int64: row c = torch.randperm(n, generator=Generator().manual_seed(seeds[c])),
+    computed on the GPU in one call (a scalar seed gives a 1-D tensor)."""
+    scalar = isinstance(seeds, int)
+    seeds = [seeds] if scalar else list(seeds)
+    out = torch.empty((len(seeds), n), dtype=torch.int64, device=device)
+    for c0 in range(0, len(seeds), 32):
+        chunk = seeds[c0:c0 + 32]
+        arr = (ctypes.c_uint64 * len(chunk))(*[s & 0xFFFFFFFFFFFFFFFF for s in chunk])
+        nbytes = lib().lbdrn_randperm_workspace(n, len(chunk))
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        check(lib().lbdrn_randperm(arr, len(chunk), n, _ptr(out[c0:]), _ptr(ws), nbytes, _stream()))
+    return out[0] if scalar else out
+
+
 def to_device_u16(arr, device):
     """numpy uint16 array -> device tensor (int16 storage, same bits)."""
     a = np.ascontiguousarray(arr, dtype=np.uint16)

@@ -36,6 +36,33 @@ def epoch_plan(epochs, val_duration):
     return plan
 
 
+class DevicePermutationStream:
+    """Same draws as PermutationStream; the permutations of all epochs are computed on the GPU by one
+    lbdrn_randperm call (the exact torch.randperm sequences, ~13 ms for ten 4 M-element orders instead
+    of 60-300 ms of host Fisher-Yates each)."""
+
+    def __init__(self, n, epochs, val_duration, device):
+        from . import ops
+        self.plan = epoch_plan(epochs, val_duration)
+        seeds, self._row = [], {}
+        for kind, e in self.plan:
+            seed = draw_iterator_seed()
+            if kind == "train":
+                self._row[e] = len(seeds)
+                seeds.append(seed)
+        self.seeds = dict(zip(self._row, seeds))
+        self._perms = ops.randperm(seeds, n, device)
+
+    def get(self, epoch):
+        return self._perms[self._row[epoch]]
+
+    def close(self):
+        self._perms = None
+
+
+GPU_RANDPERM_MAX = 0xFFFFFFFF // 20  # torch's randperm switches algorithm above this
+
+
 class PermutationStream:
     """Draws every pass's seed up front (the global generator is touched by nothing else during the
     fit) and computes the train permutations on worker threads so that the host-side Fisher-Yates

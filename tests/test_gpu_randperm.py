@@ -1,0 +1,49 @@
+"""lbdrn_randperm == torch.randperm of a seeded CPU generator, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from lbdrn_hip import ops, sampler
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 623, 624, 625, 1000, 1249, 8192, 100003, 1 << 20])
+def test_equals_torch_randperm(dev, n):
+    for seed in (0, 1, 19920517, 2 ** 40 + 17, 2 ** 63 - 1, 0xFFFFFFFF):
+        g = torch.Generator()
+        g.manual_seed(seed)
+        want = torch.randperm(n, generator=g)
+        got = ops.randperm(seed, n, dev).cpu()
+        assert torch.equal(want, got), (seed, n)
+    seeds = [5, 6, 2 ** 50 + 1] + list(range(100, 135))   # 38 seeds: two library calls
+    got = ops.randperm(seeds, n, dev).cpu()
+    for c, seed in enumerate(seeds):
+        g = torch.Generator()
+        g.manual_seed(seed)
+        assert torch.equal(torch.randperm(n, generator=g), got[c]), (seed, n)
+
+
+def test_full_size_is_a_permutation_and_matches(dev):
+    n = 2048 * 2048
+    got = ops.randperm(424242, n, dev)
+    assert int(torch.sort(got).values.ne(torch.arange(n, device=dev)).sum()) == 0
+    g = torch.Generator()
+    g.manual_seed(424242)
+    assert torch.equal(torch.randperm(n, generator=g), got.cpu())
+
+
+def test_device_stream_replays_dataloader_order(dev):
+    from torch.utils.data import DataLoader, TensorDataset
+    n, bs, epochs = 1003, 64, 3
+    torch.manual_seed(11)
+    loader = DataLoader(TensorDataset(torch.arange(n)), batch_size=bs, shuffle=True)
+    want = []
+    for _ in range(epochs):
+        want.append(torch.cat([b[0] for b in loader]))
+        for _ in loader:
+            pass
+    torch.manual_seed(11)
+    st = sampler.DevicePermutationStream(n, epochs, 1, dev)
+    for e in range(1, epochs + 1):
+        assert torch.equal(st.get(e).cpu(), want[e - 1])
