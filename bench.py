@@ -75,8 +75,10 @@ def event_time_ms(fn, stream, repeat=1):
 
 
 def roofline_probe(codec, ops, fit, img_d, a, path):
-    """HIP-event timing, on the launch stream, of the kernels the run is made of (same process, same
-    tile, right after the timed region).  Reported for the dominant one."""
+    """Live HIP-event timing, on the launch stream, right after the timed region (same process, same
+    tile).  Dominant kernel = the fused training kernel k_train_mfma (5120 launches per tile): timed
+    alone through lbdrn_train_kernel_probe (200 back-to-back launches, no reduce/Adam in between).  The
+    train+reduce pair and the fused apply kernel are reported beside it."""
     stream = torch.cuda.current_stream()
     geom, net = fit.geom, fit.net
     N = geom.H * geom.W
@@ -85,27 +87,40 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     p = fit.best_params
     ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws)
     t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws), stream, 3)
-    # one training epoch on scratch weights
     perm = torch.randperm(N, device=img_d.device)
     pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
     tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path)
-    t_train = event_time_ms(lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0,
+    t_epoch = event_time_ms(lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0,
                                                     1e-6, None, path, tws), stream, 1)
     nsteps = (N + a.bs - 1) // a.bs
     peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
-    eval_tf = fwd * N / (t_eval * 1e-3) / 1e12
-    train_tf = step * N / (t_train * 1e-3) / 1e12
-    dominant_train = a.epochs * t_train >= a.epochs * t_eval
-    ach = train_tf if dominant_train else eval_tf
-    return {
-        "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(ach / peak, 4), "traffic": None,
-        "kernel": "train step (gather+fwd+bwd+Adam, per 8192-row minibatch)" if dominant_train
-                  else "fused apply (gather+fwd+SSE)",
-        "train_step_us": round(t_train * 1e3 / nsteps, 2), "train_tflops": round(train_tf, 3),
-        "eval_pass_ms": round(t_eval, 3), "eval_tflops": round(eval_tf, 3),
-        "hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1),
-    }
+    B = min(a.bs, N)
+    out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "traffic": None}
+    try:
+        reps = 200
+        ops.train_kernel_probe(geom, net, perm, a.bs, pp, 5, tws)
+        t_k = event_time_ms(lambda: ops.train_kernel_probe(geom, net, perm, a.bs, pp, reps, tws), stream, 1) / reps
+        ach = step * B / (t_k * 1e-3) / 1e12
+        out.update({"kernel": "k_train_mfma (gather+forward+loss+backward+dW slab, one 8192-row minibatch)",
+                    "kernel_us": round(t_k * 1e3, 2), "flop_per_launch": step * B})
+    except ops._lib.LbdrnError:   # shape without an MFMA train kernel: report the generic step
+        t_k = t_epoch / nsteps
+        ach = step * B / (t_k * 1e-3) / 1e12
+        out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
+    out.update({"achieved": round(ach, 3), "frac": round(ach / peak, 4),
+                "train_step_pair_us": round(t_epoch * 1e3 / nsteps, 2),
+                "train_step_pair_tflops": round(step * N / (t_epoch * 1e-3) / 1e12, 3),
+                "apply_pass_ms": round(t_eval, 3), "apply_tflops": round(fwd * N / (t_eval * 1e-3) / 1e12, 3),
+                "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1)})
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")   # committed rocprofv3 --pmc summary, if any
+    if os.path.exists(pmc):
+        try:
+            d = json.load(open(pmc))
+            out["traffic"] = d.get("k_train_mfma_hbm_bytes_per_launch")
+            out["traffic_source"] = d.get("source")
+        except Exception:
+            pass
+    return out
 
 
 def cpu_baseline(a):

@@ -129,6 +129,14 @@ int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t 
                       double lr, float *losses, void *workspace, size_t workspace_bytes,
                       int32_t path, void *stream);
 
+/* Measurement aid (bench.py roofline leg): launches ONLY the fused gather+forward+backward kernel of
+ * the MFMA training path `repeats` times back to back on the first minibatch of perm, without the
+ * reduce/Adam launch, so that HIP events around the call time that kernel alone.  Parameters and
+ * optimiser state are not modified.  LBDRN_E_UNSUPPORTED when the shape has no MFMA path. */
+int lbdrn_train_kernel_probe(const lbdrn_geom *g, const lbdrn_net *net, const int64_t *perm, int64_t n,
+                             int32_t batch_size, const float *params, int32_t repeats, void *workspace,
+                             size_t workspace_bytes, void *stream);
+
 /* a4 -- the minibatch order: perm[0..n) = torch.randperm(n, generator=torch.Generator().manual_seed(seed))
  * of a CPU generator, bit for bit (the call RandomSampler.__iter__ makes for DataLoader(shuffle=True),
  * torch/utils/data/sampler.py:163-183, behind encode.py:69-70), computed on the GPU.  Supported for

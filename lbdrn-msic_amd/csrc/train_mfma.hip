@@ -716,6 +716,31 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     return 0;
 }
 
+// measurement aid: the fused kernel alone, `repeats` launches on the first minibatch (see lbdrn_hip.h)
+int mfma_train_probe(const lbdrn_geom& g, const lbdrn_net& net, const int64_t* perm, int64_t n, int bs,
+                     const float* params, int repeats, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    TrainArgs A;
+    if (!make_train_plan(g, net, &A.p)) return LBDRN_E_UNSUPPORTED;
+    const TrainWsLayout L = train_ws_layout(g, net, A.p, bs);
+    if (!ws || ws_bytes < L.total) {
+        set_error("train workspace too small: %zu < %zu", ws_bytes, L.total);
+        return LBDRN_E_WORKSPACE;
+    }
+    float* packed = (float*)((char*)ws + L.off_pack);
+    LBDRN_HIP_TRY(hipMemsetAsync(packed, 0, (size_t)A.p.pack_floats * sizeof(float), s));
+    k_pack_train<<<(unsigned)((A.p.NP + 255) / 256), 256, 0, s>>>(params, A.p, net.F, net.nl, net.C, packed);
+    LBDRN_LAUNCH_CHECK();
+    A.net = net; A.rows = (float*)((char*)ws + L.off_rows); A.npix = (int64_t)g.H * g.W; A.params = params;
+    A.packed = packed; A.slabs = (float*)((char*)ws + L.off_slab);
+    A.loss_part = (double*)((char*)ws + L.off_loss); A.stamps = nullptr;
+    const int B = (int)std::min<int64_t>(bs, n);
+    A.perm = perm; A.batch_n = B; A.inv = 1.0f / ((float)B * (float)net.C);
+    for (int r = 0; r < repeats; ++r)
+        if (int rc = dispatch_train(A, (B + TB - 1) / TB, s)) return rc;
+    return 0;
+}
+
 int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
