@@ -97,7 +97,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     B = min(a.bs, N)
     out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "traffic": None}
     try:
-        reps = 200
+        reps = 256
         ops.train_kernel_probe(geom, net, perm, a.bs, pp, 5, tws)
         t_k = event_time_ms(lambda: ops.train_kernel_probe(geom, net, perm, a.bs, pp, reps, tws), stream, 1) / reps
         ach = step * B / (t_k * 1e-3) / 1e12

@@ -18,6 +18,8 @@
 //    conflict-free ds_read_b64; the D-ring of normalised MSB values is staged per 16x64 tile in
 //    channel-planar LDS (conflict-free for 32 consecutive pixels) with reflect padding applied.
 //  * 8 waves per CU (2 per SIMD): one wave's sin() VALU work overlaps the other's MFMAs.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "lbdrn_math.hpp"
 
@@ -163,6 +165,7 @@ struct ApplyArgs {
     uint16_t* out;        // DECODE
     float* y_out;         // DECODE, optional
     double* partial;      // EVAL: [gridDim.x]
+    int stagger;          // waves 4-7 start each tile this many x 1024 cycles late (0 = lockstep)
 };
 
 template <int NT>
@@ -251,6 +254,12 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
         }
         __syncthreads();
 
+        // The two waves of a SIMD run the same program; started together they issue their MFMA phases at
+        // the same time and their sin() phases at the same time, and neither overlaps.  Delaying the
+        // second-dispatched half (waves 4-7, MI355X guide "Two waves per SIMD", item 9) by about one
+        // layer-0 phase puts one wave's VALU work under the other's MFMAs.
+        if (A.stagger > 0 && __builtin_amdgcn_readfirstlane(wave) >= APPLY_WAVES / 2)
+            for (int k = 0; k < A.stagger; ++k) __builtin_amdgcn_s_sleep(16);
         const int nseg = p.TH * (TILE_W / 32);
         for (int seg = wave; seg < nseg; seg += APPLY_WAVES) {
             const int ly = seg / (TILE_W / 32), lx = (seg % (TILE_W / 32)) * 32;
@@ -410,6 +419,10 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
     LBDRN_LAUNCH_CHECK();
     A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
     A.partial = partial;
+    {
+        static const int stagger = [] { const char* e = getenv("LBDRN_APPLY_STAGGER"); return e ? atoi(e) : 0; }();
+        A.stagger = stagger;
+    }
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

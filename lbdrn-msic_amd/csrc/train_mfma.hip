@@ -120,7 +120,7 @@ bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net)
 }
 
 struct TrainWsLayout {
-    size_t off_rows, off_pack, off_slab, off_loss, total;
+    size_t off_rows, off_pack, off_slab, off_loss, off_stage, stage_bytes, off_map, total;
 };
 
 static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, const TrainPlan& p, int bs)
@@ -132,6 +132,9 @@ static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, 
     const size_t nwg = (size_t)(bs + TB - 1) / TB;
     L.off_slab = o; o += align_up(nwg * (size_t)p.slab_floats * sizeof(float), 256);
     L.off_loss = o; o += align_up(nwg * sizeof(double), 256);
+    L.stage_bytes = align_up(nwg * (size_t)TB * p.RP * sizeof(float), 256);  // one minibatch of rows, contiguous
+    L.off_stage = o; o += 2 * L.stage_bytes;
+    L.off_map = o; o += align_up((size_t)p.slab_floats * 2 * sizeof(int), 256);  // slab element -> (param, fragment slot)
     L.total = o;
     return L;
 }
@@ -181,25 +184,28 @@ __global__ void __launch_bounds__(256)
 }
 
 // canonical parameter index -> position in the fragment-order buffer (or -1: not packed).
-// Quarter-K order: MFMA step s of lane quarter q multiplies k = q*L + s.
+// Quarter-K order: MFMA step s of lane quarter q multiplies k = q*L + s.  Four consecutive steps of a
+// lane are adjacent ([step/4][lane][step%4]) so that the prefetch is one 16-byte load per four steps.
 __device__ __forceinline__ int frag_pos(int64_t idx, const TrainPlan& p, int F, int nl, int C)
 {
     if (idx < p.offB[0]) {  // W0[n][k]
         int n = (int)(idx / F), k = (int)(idx - (int64_t)n * F);
         int q = k / p.LQ, s = k - q * p.LQ;
-        return p.pk_w0 + (((n >> 4) * p.LQ + s) * 64 + q * 16 + (n & 15));
+        return p.pk_w0 + ((((n >> 4) * (p.LQ >> 2) + (s >> 2)) * 64 + q * 16 + (n & 15)) * 4 + (s & 3));
     }
     for (int l = 1; l < nl; ++l) {
         if (idx >= p.offW[l] && idx < p.offB[l]) {  // W_l[n][k]
             int e = (int)(idx - p.offW[l]);
             int n = e >> 6, k = e & 63;
-            return p.pk_wh + ((((l - 1) * 4 + (n >> 4)) * 16 + (k & 15)) * 64 + (k >> 4) * 16 + (n & 15));
+            int sq = k & 15;
+            return p.pk_wh + (((((l - 1) * 4 + (n >> 4)) * 4 + (sq >> 2)) * 64 + (k >> 4) * 16 + (n & 15)) * 4 + (sq & 3));
         }
     }
     if (idx >= p.offW[nl] && idx < p.offB[nl]) {  // W_last[c][k]
         int e = (int)(idx - p.offW[nl]);
         int c = e >> 6, k = e & 63;
-        return p.pk_wl + ((k & 15) * 64 + (k >> 4) * 16 + c);
+        int sq = k & 15;
+        return p.pk_wl + (((sq >> 2) * 64 + (k >> 4) * 16 + c) * 4 + (sq & 3));
     }
     return -1;
 }
@@ -238,89 +244,71 @@ __global__ void __launch_bounds__(256)
     if (pos >= 0) packed[pos] = params[idx];
 }
 
-// g = sum over workgroups (index order within a slice, slices in order) of slab[wg][e];
-// torch Adam (torch/optim/adam.py single-tensor path: lerp_, mul_/addcmul_, addcdiv_); refresh the
-// fragment copy.  Block = RED_LANES float4 lanes x RED_SLICES workgroup slices.  While the slab reads are
-// in flight the block also touches its share of the NEXT minibatch's index slice and feature rows, so
-// that the following train kernel finds them in the Infinity Cache instead of HBM.
+// map[e] = (canonical parameter index or -1, fragment-order slot or -1) of slab element e: the index
+// arithmetic (integer divisions by F and LQ) is done once per epoch call, not in every reduce launch
 __global__ void __launch_bounds__(256)
-    k_reduce_adam(const float* __restrict__ slabs, int nwg, TrainPlan p, int F, int nl, int C,
+    k_build_map(TrainPlan p, int F, int nl, int C, int2* __restrict__ map)
+{
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.slab_floats) return;
+    int64_t idx = e < p.sl_bias + nl * TBC + 16 ? slab_to_param(e, p, F, nl, C) : -1;
+    map[e] = make_int2((int)idx, idx >= 0 ? frag_pos(idx, p, F, nl, C) : -1);
+}
+
+// g[e] = sum over workgroups of slab[wg][e], in a fixed order (slices of nwg/RED_SLICES slabs summed in
+// index order, then the slices in index order: bitwise reproducible, no atomics); torch Adam
+// (torch/optim/adam.py single-tensor path: lerp_, mul_/addcmul_, addcdiv_); refresh the fragment copy.
+// Block = RED_LANES float4 lanes (32 slab elements) x RED_SLICES workgroup slices; the final sum over
+// slices and the update are spread over 32 threads, one slab element each.
+__global__ void __launch_bounds__(256)
+    k_reduce_adam(const float* __restrict__ slabs, int nwg, int slab_floats, const int2* __restrict__ map,
                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                   float* __restrict__ packed, float step_size, float bc2_sqrt,
-                  const double* __restrict__ loss_part, double loss_count, float* loss_out,
-                  const int64_t* __restrict__ next_perm, int next_n, const float* __restrict__ rows, int64_t npix)
+                  const double* __restrict__ loss_part, double loss_count, float* loss_out)
 {
-    __shared__ float4 part[RED_SLICES][RED_LANES];
+    __shared__ float part[RED_SLICES][4 * RED_LANES + 1];
     const int l16 = threadIdx.x % RED_LANES, slice = threadIdx.x / RED_LANES;
-    const int base = blockIdx.x * (4 * RED_LANES) + 4 * l16;
-    // prefetch (result unused): row r of the next minibatch, 16 B per thread, strided over the grid
-    if (next_n > 0) {
-        const int rp4 = p.RP >> 2;
-        const int64_t total = (int64_t)next_n * rp4;
-        float keep = 0.0f;
-        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-            const int r = (int)(e / rp4), c4 = (int)(e - (int64_t)r * rp4);
-            int64_t pix = next_perm[r];
-            pix = pix < 0 ? 0 : (pix >= npix ? npix - 1 : pix);
-            const float4 t = *reinterpret_cast<const float4*>(rows + (size_t)pix * p.RP + 4 * c4);
-            keep += t.x;
-        }
-        asm volatile("" ::"v"(keep));
+    const int base = blockIdx.x * (4 * RED_LANES);
+    // the 32 updating threads fetch their parameter's state while the slab reads fly
+    int2 me = make_int2(-1, -1);
+    float pm = 0.f, pv = 0.f, pp = 0.f;
+    if (threadIdx.x < 4 * RED_LANES) {
+        me = map[base + threadIdx.x];
+        const int j = me.x < 0 ? 0 : me.x;
+        pm = m[j]; pv = v[j]; pp = params[j];
     }
     const int per = (nwg + RED_SLICES - 1) / RED_SLICES;
     const int w0 = slice * per, w1 = min(nwg, w0 + per);
-    // slice 0 owns the update of its four parameters: fetch their state while the slab reads fly
-    int64_t pidx[4];
-    float pm[4], pv[4], pp[4];
-    if (slice == 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pidx[u] = slab_to_param(base + u, p, F, nl, C);
-            const int64_t j = pidx[u] < 0 ? 0 : pidx[u];
-            pm[u] = m[j]; pv[u] = v[j]; pp[u] = params[j];
-        }
-    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* src = slabs + base;
+    const float* src = slabs + base + 4 * l16;
     int w = w0;
     for (; w + 8 <= w1; w += 8) {  // eight loads in flight, added in index order
         float4 t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u) * p.slab_floats);
+        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u) * slab_floats);
 #pragma unroll
         for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
     }
     for (; w < w1; ++w) {
-        float4 t = *reinterpret_cast<const float4*>(src + (size_t)w * p.slab_floats);
+        float4 t = *reinterpret_cast<const float4*>(src + (size_t)w * slab_floats);
         acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
-    part[slice][l16] = acc;
+    part[slice][4 * l16 + 0] = acc.x; part[slice][4 * l16 + 1] = acc.y;
+    part[slice][4 * l16 + 2] = acc.z; part[slice][4 * l16 + 3] = acc.w;
     __syncthreads();
-    if (slice == 0) {
-        float4 gsum = part[0][l16];
+    if (threadIdx.x < 4 * RED_LANES && me.x >= 0) {
+        float g = part[0][threadIdx.x];
 #pragma unroll
-        for (int s = 1; s < RED_SLICES; ++s) {
-            float4 t = part[s][l16];
-            gsum.x += t.x; gsum.y += t.y; gsum.z += t.z; gsum.w += t.w;
-        }
-        const float gv[4] = {gsum.x, gsum.y, gsum.z, gsum.w};
+        for (int s = 1; s < RED_SLICES; ++s) g += part[s][threadIdx.x];
         const float w1c = (float)(1.0 - 0.9), b2 = 0.999f, w2c = (float)(1.0 - 0.999), eps = 1e-8f;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t idx = pidx[u];
-            if (idx >= 0) {
-                const float g = gv[u];
-                float mi = pm[u] + w1c * (g - pm[u]);
-                float vi = pv[u] * b2 + w2c * (g * g);
-                float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
-                float pi = pp[u] + (-step_size) * (mi / denom);
-                m[idx] = mi;
-                v[idx] = vi;
-                params[idx] = pi;
-                int pos = frag_pos(idx, p, F, nl, C);
-                if (pos >= 0) packed[pos] = pi;
-            }
-        }
+        float mi = pm + w1c * (g - pm);
+        float vi = pv * b2 + w2c * (g * g);
+        float denom = __builtin_sqrtf(vi) / bc2_sqrt + eps;
+        float pi = pp + (-step_size) * (mi / denom);
+        m[me.x] = mi;
+        v[me.x] = vi;
+        params[me.x] = pi;
+        if (me.y >= 0) packed[me.y] = pi;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
         double s = 0.0;
@@ -343,6 +331,10 @@ struct TrainArgs {
     float* slabs;           // [nwg][slab_floats]
     double* loss_part;      // [nwg]
     float inv;              // 1 / (batch_n * C)
+    const float* stage_in;  // [nwg][32][RP] rows of THIS minibatch, staged by the previous launch (or null)
+    float* stage_out;       // where to stage the NEXT minibatch's rows (or null)
+    const int64_t* perm_next;
+    int next_n;
     unsigned long long* stamps;  // diagnostic build only (-DLBDRN_TRAIN_STAMPS): [nwg][16] s_memtime
 };
 
@@ -401,26 +393,50 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 #endif
     STAMP(0);
 
-    // the one load everything else waits for goes first, so that the wait for it leaves the weight
-    // prefetch below in flight (vmcnt retires in issue order)
+    // Where the rows come from.  The random-access gather of a minibatch (8192 x 832 B from a 3.5 GB
+    // matrix, ~5 us of exposed latency when done at the top of the step that needs it) is taken off
+    // the critical path: launch s loads the rows of minibatch s+1 into registers right at its start,
+    // lets the loads fly during its own compute and parks them, contiguous, in a staging buffer at its
+    // end; launch s+1 then starts from a coalesced 26 KB read.  Only the first step of an epoch
+    // gathers for itself.
+    const bool staged = A.stage_in != nullptr;
     int64_t mypix = 0;
-    if (tid < TB) mypix = A.perm[first + min(tid, nvalid - 1)];
+    if (!staged && tid < TB) mypix = A.perm[first + min(tid, nvalid - 1)];
+    const int rs = tid >> 4, rsub = tid & 15;  // row copy: 16 threads per row
+    int64_t nextpix = -1;
+    // (rows past the end of a short minibatch repeat its last row, like the direct gather does: they
+    //  are masked out of the loss but must hold finite values)
+    if (A.stage_out && first < A.next_n) nextpix = A.perm_next[min(first + rs, A.next_n - 1)];
 
     // ---- weight prefetch: everything this wave will multiply by, L2 -> VGPR, before the gather
     float a0[LQ];
     {
-        const float* wf0 = A.packed + p.pk_w0 + (size_t)w * LQ * 64 + lane;
+        const float4* wf0 = reinterpret_cast<const float4*>(A.packed + p.pk_w0) + (size_t)w * (LQ / 4) * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < LQ; ++s) a0[s] = wf0[s * 64];
+        for (int g = 0; g < LQ / 4; ++g) {
+            const float4 t = wf0[g * 64];
+            a0[4 * g] = t.x; a0[4 * g + 1] = t.y; a0[4 * g + 2] = t.z; a0[4 * g + 3] = t.w;
+        }
     }
     float ah[NL > 1 ? NL - 1 : 1][16];
 #pragma unroll
-    for (int l = 1; l < NL; ++l)
+    for (int l = 1; l < NL; ++l) {
+        const float4* wfh = reinterpret_cast<const float4*>(A.packed + p.pk_wh) + (size_t)((l - 1) * 4 + w) * 4 * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) ah[l - 1][s] = A.packed[p.pk_wh + (((l - 1) * 4 + w) * 16 + s) * 64 + lane];
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = wfh[g * 64];
+            ah[l - 1][4 * g] = t.x; ah[l - 1][4 * g + 1] = t.y; ah[l - 1][4 * g + 2] = t.z; ah[l - 1][4 * g + 3] = t.w;
+        }
+    }
     float al[16];
+    {
+        const float4* wfl = reinterpret_cast<const float4*>(A.packed + p.pk_wl) + lane;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) al[s] = A.packed[p.pk_wl + s * 64 + lane];
+        for (int g = 0; g < 4; ++g) {
+            const float4 t = wfl[g * 64];
+            al[4 * g] = t.x; al[4 * g + 1] = t.y; al[4 * g + 2] = t.z; al[4 * g + 3] = t.w;
+        }
+    }
     float atl[4];  // W_last^T: A[i = hidden 16w+i][k = channel 4q+s]
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -443,26 +459,37 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? A.params[p.offB[NL] + 4 * q + r] : 0.0f;
 
     // ---- phase 0: which rows
-    if (tid < TB) {
-        int64_t pix = mypix < 0 ? 0 : (mypix >= A.npix ? A.npix - 1 : mypix);
-        pixs[tid] = (int)pix;
+    if (!staged) {
+        if (tid < TB) {
+            int64_t pix = mypix < 0 ? 0 : (mypix >= A.npix ? A.npix - 1 : mypix);
+            pixs[tid] = (int)pix;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     STAMP(1);
     // ---- phase 1: copy the 32 rows (features | labels) into LDS, row-major (X) and transposed (XT):
     //      16 threads per row, 16 B per load, all loads issued before the first store
     //      (a4: ref LBDRNdataset.py:151-155)
+    constexpr int NLD = (XP / 4 + 15) / 16;
+    const int rp4 = p.RP >> 2;
+    float4 vnext[NLD];
     {
-        const int s = tid >> 4, sub = tid & 15;
-        const float* src = A.rows + (size_t)pixs[s] * p.RP;
+        const int s = rs, sub = rsub;
+        const float* src = staged ? A.stage_in + ((size_t)wg * TB + s) * p.RP : A.rows + (size_t)pixs[s] * p.RP;
         float* xr = Xs + s * XP;
-        const int rp4 = p.RP >> 2, nt16 = 16 * p.NT0;
-        constexpr int NLD = (XP / 4 + 15) / 16;
+        const int nt16 = 16 * p.NT0;
         float4 v[NLD];
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             int c4 = min(sub + 16 * u, rp4 - 1);  // clamped: never a load behind a branch
             v[u] = *reinterpret_cast<const float4*>(src + 4 * c4);
+        }
+        // the next minibatch's rows: issued now, consumed at the very end of the kernel
+        {
+            const int64_t np = nextpix < 0 ? 0 : (nextpix >= A.npix ? A.npix - 1 : nextpix);
+            const float* nsrc = A.rows + (size_t)np * p.RP;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) vnext[u] = *reinterpret_cast<const float4*>(nsrc + 4 * min(sub + 16 * u, rp4 - 1));
         }
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
@@ -647,6 +674,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
         slab[p.sl_bias + u] = v;
     }
     for (int u = p.sl_bias + NL * TBC + 16 + tid; u < p.slab_floats; u += TRAIN_THREADS) slab[u] = 0.0f;
+    if (nextpix >= 0) {  // park the next minibatch's rows (loaded at kernel start) in the staging buffer
+        float* dstn = A.stage_out + ((size_t)wg * TB + rs) * p.RP;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int c4 = rsub + 16 * u;
+            if (c4 < rp4) *reinterpret_cast<float4*>(dstn + 4 * c4) = vnext[u];
+        }
+    }
     STAMP(8);
 #ifdef LBDRN_TRAIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -734,10 +769,22 @@ int mfma_train_probe(const lbdrn_geom& g, const lbdrn_net& net, const int64_t* p
     A.net = net; A.rows = (float*)((char*)ws + L.off_rows); A.npix = (int64_t)g.H * g.W; A.params = params;
     A.packed = packed; A.slabs = (float*)((char*)ws + L.off_slab);
     A.loss_part = (double*)((char*)ws + L.off_loss); A.stamps = nullptr;
+    // walk the permutation like an epoch does (fresh random rows every launch, next minibatch staged by
+    // the current launch) so that cache behaviour matches the real sequence; only the reduce/Adam
+    // launches are left out
+    float* stage[2] = {(float*)((char*)ws + L.off_stage), (float*)((char*)ws + L.off_stage + L.stage_bytes)};
+    const int64_t nfull = std::max<int64_t>(1, n / bs);   // full minibatches available
     const int B = (int)std::min<int64_t>(bs, n);
-    A.perm = perm; A.batch_n = B; A.inv = 1.0f / ((float)B * (float)net.C);
-    for (int r = 0; r < repeats; ++r)
+    A.batch_n = B; A.inv = 1.0f / ((float)B * (float)net.C);
+    for (int r = 0; r < repeats; ++r) {
+        const int64_t cur = (r % nfull) * (int64_t)bs, nxt = ((r + 1) % nfull) * (int64_t)bs;
+        A.perm = perm + cur;
+        A.stage_in = r > 0 ? stage[r & 1] : nullptr;
+        A.stage_out = stage[(r + 1) & 1];
+        A.perm_next = perm + nxt;
+        A.next_n = B;
         if (int rc = dispatch_train(A, (B + TB - 1) / TB, s)) return rc;
+    }
     return 0;
 }
 
@@ -765,6 +812,10 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
     LBDRN_LAUNCH_CHECK();
     A.net = net; A.rows = rows; A.npix = (int64_t)g.H * g.W; A.params = params; A.packed = packed;
     A.slabs = slabs; A.loss_part = loss_part;
+    int2* map = (int2*)((char*)ws + L.off_map);
+    k_build_map<<<(unsigned)((A.p.slab_floats + 255) / 256), 256, 0, s>>>(A.p, net.F, net.nl, net.C, map);
+    LBDRN_LAUNCH_CHECK();
+    float* stage[2] = {(float*)((char*)ws + L.off_stage), (float*)((char*)ws + L.off_stage + L.stage_bytes)};
     A.stamps = nullptr;
 #ifdef LBDRN_TRAIN_STAMPS
     const int max_wg = (bs + TB - 1) / TB;
@@ -778,13 +829,17 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
         A.perm = perm + first;
         A.batch_n = B;
         A.inv = 1.0f / ((float)B * (float)net.C);
+        const int64_t nextB = std::max<int64_t>(0, std::min<int64_t>(bs, n - first - bs));
+        A.stage_in = si > 0 ? stage[si & 1] : nullptr;          // staged by the previous launch
+        A.stage_out = nextB > 0 ? stage[(si + 1) & 1] : nullptr;
+        A.perm_next = perm + first + bs;
+        A.next_n = (int)nextB;
         if (int rc = dispatch_train(A, nwg, s)) return rc;
         ++step;
         const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
         k_reduce_adam<<<(unsigned)(A.p.slab_floats / (4 * RED_LANES)), 256, 0, s>>>(
-            slabs, nwg, A.p, net.F, net.nl, net.C, params, m, v, packed, (float)(lr / bc1),
-            (float)std::sqrt(bc2), loss_part, (double)B * net.C, losses ? losses + si : nullptr,
-            perm + first, 0 /* next-batch prefetch: measured slower (+2.9 us in this kernel, -0.6 us in the next) */, rows, A.npix);
+            slabs, nwg, A.p.slab_floats, map, params, m, v, packed, (float)(lr / bc1), (float)std::sqrt(bc2),
+            loss_part, (double)B * net.C, losses ? losses + si : nullptr);
         LBDRN_LAUNCH_CHECK();
     }
 #ifdef LBDRN_TRAIN_STAMPS

@@ -61,8 +61,31 @@ void run(const char* name, K kern, int threads, int chains, int nblk)
            chains, nblk, m / (iters * 8.0 * chains), m / (iters * 8.0 * chains) / (waves_per_simd ? waves_per_simd : 1));
     hipFree(out); hipFree(cyc);
 }
+template <class K>
+void wall(const char* name, K kern, int threads, int chains, double flop_per_mfma)
+{
+    float* out; unsigned long long* cyc;
+    const int nblk = 256 * (1024 / threads > 2 ? 2 : 1) ;
+    hipMalloc(&out, sizeof(float) * threads * nblk); hipMalloc(&cyc, 8 * nblk);
+    const int iters = 20000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    kern<<<nblk, threads>>>(out, cyc, 100);
+    hipEventRecord(a);
+    kern<<<nblk, threads>>>(out, cyc, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    double mfmas = (double)nblk * (threads / 64) * iters * 8.0 * chains;
+    printf("WALL %-10s threads=%4d chains=%d blocks=%d : %.2f ms -> %.1f TFLOP/s\n", name, threads, chains, nblk, ms,
+           mfmas * flop_per_mfma / (ms * 1e-3) / 1e12);
+    hipFree(out); hipFree(cyc);
+}
 int main()
 {
+    wall("16x16x4", k16<2>, 256, 2, 2048.0);
+    wall("16x16x4", k16<2>, 512, 2, 2048.0);
+    wall("16x16x4", k16<1>, 1024, 1, 2048.0);
+    wall("32x32x2", k32<2>, 256, 2, 4096.0);
+    wall("32x32x2", k32<2>, 512, 2, 4096.0);
     for (int nblk : {1, 256}) {
         run("16x16x4", k16<1>, 256, 1, nblk);
         run("16x16x4", k16<2>, 256, 2, nblk);
