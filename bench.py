@@ -76,9 +76,9 @@ def event_time_ms(fn, stream, repeat=1):
 
 def roofline_probe(codec, ops, fit, img_d, a, path):
     """Live HIP-event timing, on the launch stream, right after the timed region (same process, same
-    tile).  Dominant kernel = the fused training kernel k_train_mfma (5120 launches per tile): timed
-    alone through lbdrn_train_kernel_probe (200 back-to-back launches, no reduce/Adam in between).  The
-    train+reduce pair and the fused apply kernel are reported beside it."""
+    tile).  Dominant kernel = the fused training kernel k_train_mfma (5120 launches per tile): every one of
+    its 512 launches in one real epoch (train, reduce/Adam, train, ...) is bracketed by its own event pair
+    (lbdrn_train_profile_begin/end).  The train+reduce pair and the fused apply kernel are reported beside it."""
     stream = torch.cuda.current_stream()
     geom, net = fit.geom, fit.net
     N = geom.H * geom.W
@@ -96,17 +96,26 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
     B = min(a.bs, N)
     out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "traffic": None}
+    # the dominant kernel inside the real train/reduce sequence: one epoch with the reduce launch doubled
+    # isolates the reduce kernel (t2 - t1); the rest of a step is the train kernel (plus ~0.4 us of gap)
+    run_epoch = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0, 1e-6, None, path, tws)
     try:
-        reps = 256
-        ops.train_kernel_probe(geom, net, perm, a.bs, pp, 5, tws)
-        t_k = event_time_ms(lambda: ops.train_kernel_probe(geom, net, perm, a.bs, pp, reps, tws), stream, 1) / reps
-        ach = step * B / (t_k * 1e-3) / 1e12
+        ops.train_profile_mode(1)
+        t_epoch2 = event_time_ms(run_epoch, stream, 1)
+    finally:
+        ops.train_profile_mode(0)
+    t_reduce = (t_epoch2 - t_epoch) / nsteps
+    if t_reduce > 0.5e-3:  # the MFMA path is in use (the generic path ignores the mode)
+        t_k = t_epoch / nsteps - t_reduce
         out.update({"kernel": "k_train_mfma (gather+forward+loss+backward+dW slab, one 8192-row minibatch)",
-                    "kernel_us": round(t_k * 1e3, 2), "flop_per_launch": step * B})
-    except ops._lib.LbdrnError:   # shape without an MFMA train kernel: report the generic step
+                    "kernel_us": round(t_k * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
+                    "flop_per_launch": step * B,
+                    "timing": "HIP events over one 512-step epoch, and over one with the reduce launch doubled; "
+                              "kernel_us = step - reduce, inside the real launch sequence"})
+    else:  # shape without an MFMA train kernel: the generic step is many launches
         t_k = t_epoch / nsteps
-        ach = step * B / (t_k * 1e-3) / 1e12
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
+    ach = step * B / (t_k * 1e-3) / 1e12
     out.update({"achieved": round(ach, 3), "frac": round(ach / peak, 4),
                 "train_step_pair_us": round(t_epoch * 1e3 / nsteps, 2),
                 "train_step_pair_tflops": round(step * N / (t_epoch * 1e-3) / 1e12, 3),

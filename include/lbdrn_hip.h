@@ -129,13 +129,12 @@ int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t 
                       double lr, float *losses, void *workspace, size_t workspace_bytes,
                       int32_t path, void *stream);
 
-/* Measurement aid (bench.py roofline leg): launches ONLY the fused gather+forward+backward kernel of
- * the MFMA training path `repeats` times back to back on the first minibatch of perm, without the
- * reduce/Adam launch, so that HIP events around the call time that kernel alone.  Parameters and
- * optimiser state are not modified.  LBDRN_E_UNSUPPORTED when the shape has no MFMA path. */
-int lbdrn_train_kernel_probe(const lbdrn_geom *g, const lbdrn_net *net, const int64_t *perm, int64_t n,
-                             int32_t batch_size, const float *params, int32_t repeats, void *workspace,
-                             size_t workspace_bytes, void *stream);
+/* Measurement aid (bench.py roofline leg).  mode 1: every step of lbdrn_train_epoch on this thread
+ * launches its reduce/Adam kernel twice (the second with a zero step size), mode 0: normal.  Timing one
+ * epoch in each mode with a single HIP-event pair gives t_reduce = t(mode 1) - t(mode 0) per step and
+ * t_train_kernel = t(mode 0) - t_reduce, both inside the real launch sequence and without per-launch event
+ * packets (which cost more than the ~0.4 us gaps they would measure).  Use on scratch optimiser state. */
+int lbdrn_train_profile_mode(int32_t mode);
 
 /* a4 -- the minibatch order: perm[0..n) = torch.randperm(n, generator=torch.Generator().manual_seed(seed))
  * of a CPU generator, bit for bit (the call RandomSampler.__iter__ makes for DataLoader(shuffle=True),

@@ -14,8 +14,7 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
                      size_t ws_bytes, hipStream_t s);
-int mfma_train_probe(const lbdrn_geom& g, const lbdrn_net& net, const int64_t* perm, int64_t n, int bs,
-                     const float* params, int repeats, void* ws, size_t ws_bytes, hipStream_t s);
+int train_profile_mode(int mode);
 size_t randperm_workspace(int64_t n, int count);
 int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, void* ws, size_t ws_bytes,
                    hipStream_t s);
@@ -229,21 +228,10 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-int lbdrn_train_kernel_probe(const lbdrn_geom* g, const lbdrn_net* net, const int64_t* perm, int64_t n,
-                             int32_t batch_size, const float* params, int32_t repeats, void* workspace,
-                             size_t workspace_bytes, void* stream)
+int lbdrn_train_profile_mode(int32_t mode)
 {
-    if (int rc = check_geom(g)) return rc;
-    if (int rc = check_net(net)) return rc;
-    if (int rc = net_matches(g, net)) return rc;
-    LBDRN_REQUIRE(perm && params && n >= 1 && batch_size >= 1 && repeats >= 1, "bad arguments");
-    NEED_DEVICE();
-    if (!mfma_train_supported(*g, *net)) {
-        set_error("fused MFMA train kernel does not support this shape");
-        return LBDRN_E_UNSUPPORTED;
-    }
-    return mfma_train_probe(*g, *net, perm, n, batch_size, params, repeats, workspace, workspace_bytes,
-                            (hipStream_t)stream);
+    LBDRN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");
+    return train_profile_mode(mode);
 }
 
 size_t lbdrn_randperm_workspace(int64_t n, int32_t count)

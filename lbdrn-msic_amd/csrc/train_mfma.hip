@@ -351,6 +351,29 @@ struct TrainArgs {
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// 16-byte store that writes through to memory (sc1): the gradient slab and the staged rows are consumed
+// by the NEXT launch, never by this one, so they should not sit dirty in this XCD's L2 until the
+// end-of-kernel write-back (26 MB per step, measured as ~4 us between the last wave's exit and the kernel's
+// completion); written through, they drain while the remaining phases compute.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+struct WtBuf {  // buffer descriptor of a wave-uniform region + 16-byte write-through stores into it
+    __amdgpu_buffer_rsrc_t r;
+    float* base;
+    __device__ __forceinline__ WtBuf(float* p, size_t bytes) : base(p)
+    {
+        r = __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)bytes, 0x00020000);
+    }
+    __device__ __forceinline__ void store(int float_off, float a, float b, float c, float d) const
+    {
+#ifdef LBDRN_PLAIN_SLAB_STORES
+        *reinterpret_cast<float4*>(base + float_off) = make_float4(a, b, c, d);
+#else
+        v4i32 v = {__float_as_int(a), __float_as_int(b), __float_as_int(c), __float_as_int(d)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, float_off * 4, 0, 16 /* sc1 */);
+#endif
+    }
+};
+
 // N contiguous floats (N % 4 == 0) from a 16-byte aligned LDS address into registers
 template <int N>
 __device__ __forceinline__ void lds_load(const float* src, float (&dst)[N])
@@ -387,6 +410,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     const int nvalid = min(TB, A.batch_n - first);
     const int srow = i + 16 * st;  // the sample (row of X / H / dZ) this lane's B operands come from
     float* slab = A.slabs + (size_t)wg * p.slab_floats;
+    const WtBuf slabw(slab, (size_t)p.slab_floats * 4);
 #ifdef LBDRN_TRAIN_STAMPS
     unsigned long long stamp[16] = {};
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[12])::"memory");
@@ -621,7 +645,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     // ---- phase 7: weight gradients, K = 32 samples (8 MFMA steps, quarter q walks samples 8q..8q+7):
     //      dW[16w + row][16nt + col] = sum_s dz[s][16w + row] * in[s][16nt + col]; wave (w, st) takes the
     //      column tiles nt = st, st+2, ...; each finished tile leaves as one 1 KB store in tile order.
-    auto grad_tiles = [&](const float* zt, const float* bt, int ntiles, float* out) {
+    auto grad_tiles = [&](const float* zt, const float* bt, int ntiles, int out) {
         float az[8];
         lds_load<8>(zt + (16 * w + i) * TP + 8 * q, az);
         for (int nt = st; nt < ntiles; nt += 4) {
@@ -637,18 +661,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
                 g0 = MFMA16(az[s], b0[s], g0);
                 g1 = MFMA16(az[s], b1[s], g1);
             }
-            *reinterpret_cast<float4*>(out + ((size_t)(w * ntiles + nt) * 64 + lane) * 4) =
-                make_float4(g0[0], g0[1], g0[2], g0[3]);
-            if (two)
-                *reinterpret_cast<float4*>(out + ((size_t)(w * ntiles + nt1) * 64 + lane) * 4) =
-                    make_float4(g1[0], g1[1], g1[2], g1[3]);
+            slabw.store(out + ((w * ntiles + nt) * 64 + lane) * 4, g0[0], g0[1], g0[2], g0[3]);
+            if (two) slabw.store(out + ((w * ntiles + nt1) * 64 + lane) * 4, g1[0], g1[1], g1[2], g1[3]);
         }
     };
-    grad_tiles(ZT, XT, p.NT0, slab);
+    grad_tiles(ZT, XT, p.NT0, 0);
     STAMP(10);
 #pragma unroll
     for (int l = 1; l < NL; ++l)
-        grad_tiles(ZT + (size_t)l * TBC * TP, HT + (size_t)(l - 1) * TBC * TP, 4, slab + p.sl_hid + (l - 1) * 16 * 256);
+        grad_tiles(ZT + (size_t)l * TBC * TP, HT + (size_t)(l - 1) * TBC * TP, 4, p.sl_hid + (l - 1) * 16 * 256);
     if (st == 0) {  // output layer: rows = channel slots, wave w takes hidden columns 16w..16w+15
         float az[8], bv[8];
         lds_load<8>(ZoT + i * TP + 8 * q, az);
@@ -660,8 +681,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
             g0 = MFMA16(az[s], bv[s], g0);
             g1 = MFMA16(az[s + 1], bv[s + 1], g1);
         }
-        *reinterpret_cast<float4*>(slab + p.sl_out + ((size_t)w * 64 + lane) * 4) =
-            make_float4(g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]);
+        slabw.store(p.sl_out + (w * 64 + lane) * 4, g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]);
     }
     STAMP(11);
     // bias gradients: sums over the 32 samples of one unit = one row of the transposed copies
@@ -675,11 +695,11 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     }
     for (int u = p.sl_bias + NL * TBC + 16 + tid; u < p.slab_floats; u += TRAIN_THREADS) slab[u] = 0.0f;
     if (nextpix >= 0) {  // park the next minibatch's rows (loaded at kernel start) in the staging buffer
-        float* dstn = A.stage_out + ((size_t)wg * TB + rs) * p.RP;
+        const WtBuf stw(A.stage_out + (size_t)wg * TB * p.RP, (size_t)TB * p.RP * 4);
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int c4 = rsub + 16 * u;
-            if (c4 < rp4) *reinterpret_cast<float4*>(dstn + 4 * c4) = vnext[u];
+            if (c4 < rp4) stw.store(rs * p.RP + 4 * c4, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
         }
     }
     STAMP(8);
@@ -751,40 +771,11 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     return 0;
 }
 
-// measurement aid: the fused kernel alone, `repeats` launches on the first minibatch (see lbdrn_hip.h)
-int mfma_train_probe(const lbdrn_geom& g, const lbdrn_net& net, const int64_t* perm, int64_t n, int bs,
-                     const float* params, int repeats, void* ws, size_t ws_bytes, hipStream_t s)
+// measurement aid (see lbdrn_hip.h): mode 1 doubles the reduce/Adam launch of every step
+static thread_local int g_prof_mode = 0;
+int train_profile_mode(int mode)
 {
-    TrainArgs A;
-    if (!make_train_plan(g, net, &A.p)) return LBDRN_E_UNSUPPORTED;
-    const TrainWsLayout L = train_ws_layout(g, net, A.p, bs);
-    if (!ws || ws_bytes < L.total) {
-        set_error("train workspace too small: %zu < %zu", ws_bytes, L.total);
-        return LBDRN_E_WORKSPACE;
-    }
-    float* packed = (float*)((char*)ws + L.off_pack);
-    LBDRN_HIP_TRY(hipMemsetAsync(packed, 0, (size_t)A.p.pack_floats * sizeof(float), s));
-    k_pack_train<<<(unsigned)((A.p.NP + 255) / 256), 256, 0, s>>>(params, A.p, net.F, net.nl, net.C, packed);
-    LBDRN_LAUNCH_CHECK();
-    A.net = net; A.rows = (float*)((char*)ws + L.off_rows); A.npix = (int64_t)g.H * g.W; A.params = params;
-    A.packed = packed; A.slabs = (float*)((char*)ws + L.off_slab);
-    A.loss_part = (double*)((char*)ws + L.off_loss); A.stamps = nullptr;
-    // walk the permutation like an epoch does (fresh random rows every launch, next minibatch staged by
-    // the current launch) so that cache behaviour matches the real sequence; only the reduce/Adam
-    // launches are left out
-    float* stage[2] = {(float*)((char*)ws + L.off_stage), (float*)((char*)ws + L.off_stage + L.stage_bytes)};
-    const int64_t nfull = std::max<int64_t>(1, n / bs);   // full minibatches available
-    const int B = (int)std::min<int64_t>(bs, n);
-    A.batch_n = B; A.inv = 1.0f / ((float)B * (float)net.C);
-    for (int r = 0; r < repeats; ++r) {
-        const int64_t cur = (r % nfull) * (int64_t)bs, nxt = ((r + 1) % nfull) * (int64_t)bs;
-        A.perm = perm + cur;
-        A.stage_in = r > 0 ? stage[r & 1] : nullptr;
-        A.stage_out = stage[(r + 1) & 1];
-        A.perm_next = perm + nxt;
-        A.next_n = B;
-        if (int rc = dispatch_train(A, (B + TB - 1) / TB, s)) return rc;
-    }
+    g_prof_mode = mode;
     return 0;
 }
 
@@ -840,6 +831,10 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
         k_reduce_adam<<<(unsigned)(A.p.slab_floats / (4 * RED_LANES)), 256, 0, s>>>(
             slabs, nwg, A.p.slab_floats, map, params, m, v, packed, (float)(lr / bc1), (float)std::sqrt(bc2),
             loss_part, (double)B * net.C, losses ? losses + si : nullptr);
+        if (g_prof_mode == 1)  // measurement only: the same launch again with a zero step
+            k_reduce_adam<<<(unsigned)(A.p.slab_floats / (4 * RED_LANES)), 256, 0, s>>>(
+                slabs, nwg, A.p.slab_floats, map, params, m, v, packed, 0.0f, (float)std::sqrt(bc2), loss_part,
+                (double)B * net.C, nullptr);
         LBDRN_LAUNCH_CHECK();
     }
 #ifdef LBDRN_TRAIN_STAMPS

@@ -183,10 +183,9 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
                                   ws.nbytes, path, _stream()))
 
 
-def train_kernel_probe(geom, net, perm, batch_size, params, repeats, ws):
-    """Measurement aid: `repeats` back-to-back launches of the fused MFMA train kernel alone."""
-    check(lib().lbdrn_train_kernel_probe(ctypes.byref(geom.c), ctypes.byref(net), _ptr(perm), perm.numel(),
-                                         batch_size, _ptr(params), repeats, _ptr(ws.buf), ws.nbytes, _stream()))
+def train_profile_mode(mode):
+    """Measurement aid: mode 1 makes train_epoch launch every reduce/Adam kernel twice (see lbdrn_hip.h)."""
+    check(lib().lbdrn_train_profile_mode(int(mode)))
 
 
 def train_step(net, x, t, params, exp_avg, exp_avg_sq, adam_step, lr, apply_adam=True):

@@ -37,27 +37,56 @@ def epoch_plan(epochs, val_duration):
 
 
 class DevicePermutationStream:
-    """Same draws as PermutationStream; the permutations of all epochs are computed on the GPU by one
-    lbdrn_randperm call (the exact torch.randperm sequences, ~13 ms for ten 4 M-element orders instead
-    of 60-300 ms of host Fisher-Yates each)."""
+    """Same draws as PermutationStream; the permutations are computed on the GPU by lbdrn_randperm (the
+    exact torch.randperm sequences).  The MT19937 recurrence is serial (5 ms for 4 M words, whatever the
+    number of seeds generated side by side), so the work runs on a side stream in two batches -- epoch 1
+    alone, then all the others -- and the training stream only waits for the batch it needs: the first
+    wait hides behind the row-matrix build, the second behind epoch 1."""
 
     def __init__(self, n, epochs, val_duration, device):
         from . import ops
         self.plan = epoch_plan(epochs, val_duration)
-        seeds, self._row = [], {}
+        seeds, order = [], []
         for kind, e in self.plan:
             seed = draw_iterator_seed()
             if kind == "train":
-                self._row[e] = len(seeds)
+                order.append(e)
                 seeds.append(seed)
-        self.seeds = dict(zip(self._row, seeds))
-        self._perms = ops.randperm(seeds, n, device)
+        self.seeds = dict(zip(order, seeds))
+        self._row = {e: i for i, e in enumerate(order)}
+        main = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        side.wait_stream(main)
+        self._batches = []
+        with torch.cuda.stream(side):
+            for lo, hi in ((0, 1), (1, len(seeds))):
+                if hi > lo:
+                    perms = ops.randperm(seeds[lo:hi], n, device)
+                    perms.record_stream(main)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                    self._batches.append((lo, hi, perms, ev))
 
     def get(self, epoch):
-        return self._perms[self._row[epoch]]
+        i = self._row[epoch]
+        for lo, hi, perms, ev in self._batches:
+            if lo <= i < hi:
+                torch.cuda.current_stream(perms.device).wait_event(ev)
+                return perms[i - lo]
+        raise KeyError(epoch)
 
     def close(self):
-        self._perms = None
+        self._batches = []
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
 
 
 GPU_RANDPERM_MAX = 0xFFFFFFFF // 20  # torch's randperm switches algorithm above this
