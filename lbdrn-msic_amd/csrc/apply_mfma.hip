@@ -18,8 +18,6 @@
 //    conflict-free ds_read_b64; the D-ring of normalised MSB values is staged per 16x64 tile in
 //    channel-planar LDS (conflict-free for 32 consecutive pixels) with reflect padding applied.
 //  * 8 waves per CU (2 per SIMD): one wave's sin() VALU work overlaps the other's MFMAs.
-#include <cstdlib>
-
 #include "common.hpp"
 #include "lbdrn_math.hpp"
 
@@ -165,8 +163,22 @@ struct ApplyArgs {
     uint16_t* out;        // DECODE
     float* y_out;         // DECODE, optional
     double* partial;      // EVAL: [gridDim.x]
-    int stagger;          // waves 4-7 start each tile this many x 1024 cycles late (0 = lockstep)
+    unsigned long long* stamps;  // diagnostic build (-DLBDRN_APPLY_STAMPS): [gridDim.x][8] cycle sums of wave 0
 };
+
+#ifdef LBDRN_APPLY_STAMPS
+#define ASTAMP(k)                                                                     \
+    do {                                                                              \
+        unsigned long long t_;                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");   \
+        __builtin_amdgcn_sched_barrier(0);                                            \
+        acc_t[k] += t_ - last_t;                                                      \
+        last_t = t_;                                                                  \
+    } while (0)
+#else
+#define ASTAMP(k)
+#endif
 
 template <int NT>
 __device__ __forceinline__ void load_a(const float* w, int idx, float (&a)[NT])
@@ -229,6 +241,10 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
     const int lmask = (1 << g.K) - 1;
     double sse = 0.0;
 
+#ifdef LBDRN_APPLY_STAMPS
+    unsigned long long acc_t[8] = {}, last_t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t)::"memory");
+#endif
     const int ntiles = p.tiles_x * p.tiles_y;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
@@ -236,12 +252,39 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
         __syncthreads();  // previous tile fully consumed (and the weight copy landed)
         // ---- stage the (TH+2D) x (64+2D) ring: p = float(msb)/max, reflect-padded (LBDRNdataset.py:120-123)
         if (g.use_colors) {
+            // element e = (c, sy, sx) in LDS order, consecutive lanes = consecutive columns of one row, so a
+            // wave load is one or two full 128-byte lines of the uint16 plane.  Eight loads are issued
+            // before the first division (a load -> divide -> store loop paid the memory latency once per
+            // element: 27 % of the kernel).  Index split by multiply-high (exact for e < 2^16, SW,SH < 2^8).
             const int plane = p.SH * p.SW, total = C * plane;
-            for (int e = tid; e < total; e += APPLY_THREADS) {
-                int c = e / plane, r = e - c * plane;
-                int sy = r / p.SW, sx = r - sy * p.SW;
-                int yy = reflect_fast(y0 + sy - D, g.H), xx = reflect_fast(x0 + sx - D, g.W);
-                tile[e] = (float)A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx] / maxf;
+            const unsigned msw = 0xFFFFFFFFu / (unsigned)p.SW + 1u, msh = 0xFFFFFFFFu / (unsigned)p.SH + 1u;
+            const bool simple = D < g.H && D < g.W && total < 65536;
+            constexpr int UB = 8;
+            for (int base = 0; base < total; base += APPLY_THREADS * UB) {
+                unsigned short raw[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = min(base + u * APPLY_THREADS + tid, total - 1);
+                    int row, sx, c, sy, yy, xx;
+                    if (simple) {
+                        row = (int)__umulhi((unsigned)e, msw); sx = e - row * p.SW;
+                        c = (int)__umulhi((unsigned)row, msh); sy = row - c * p.SH;
+                        yy = y0 + sy - D; xx = x0 + sx - D;
+                        yy = yy < 0 ? -yy : yy; yy = yy >= g.H ? 2 * (g.H - 1) - yy : yy;
+                        xx = xx < 0 ? -xx : xx; xx = xx >= g.W ? 2 * (g.W - 1) - xx : xx;
+                        yy = max(0, min(yy, g.H - 1));  // rows / columns past a ragged last tile feed only
+                        xx = max(0, min(xx, g.W - 1));  // masked outputs: any valid pixel will do
+                    } else {
+                        row = e / p.SW; sx = e - row * p.SW; c = row / p.SH; sy = row - c * p.SH;
+                        yy = reflect_idx(y0 + sy - D, g.H); xx = reflect_idx(x0 + sx - D, g.W);
+                    }
+                    raw[u] = A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx];
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int e = base + u * APPLY_THREADS + tid;
+                    if (e < total) tile[e] = (float)raw[u] / maxf;
+                }
             }
         }
         for (int e = tid; e < p.TH * P; e += APPLY_THREADS) {
@@ -254,16 +297,26 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
         }
         __syncthreads();
 
-        // The two waves of a SIMD run the same program; started together they issue their MFMA phases at
-        // the same time and their sin() phases at the same time, and neither overlaps.  Delaying the
-        // second-dispatched half (waves 4-7, MI355X guide "Two waves per SIMD", item 9) by about one
-        // layer-0 phase puts one wave's VALU work under the other's MFMAs.
-        if (A.stagger > 0 && __builtin_amdgcn_readfirstlane(wave) >= APPLY_WAVES / 2)
-            for (int k = 0; k < A.stagger; ++k) __builtin_amdgcn_s_sleep(16);
+        ASTAMP(0);  // staging + barriers
         const int nseg = p.TH * (TILE_W / 32);
         for (int seg = wave; seg < nseg; seg += APPLY_WAVES) {
             const int ly = seg / (TILE_W / 32), lx = (seg % (TILE_W / 32)) * 32;
             const int pixbase = (ly + D) * p.SW + (lx + j + D);
+            // what the epilogue needs from HBM (the label source or the MSB to rebuild) is requested now, so
+            // that its latency hides behind the layer-0 MFMAs instead of ending the block
+            const int yy = y0 + ly, xx = x0 + lx + j;
+            const bool inside = yy < g.H && xx < g.W;
+            const int64_t pix = (int64_t)min(yy, g.H - 1) * g.W + min(xx, g.W - 1);
+            const int nreg = 4 * ((C + 7) / 8);  // accumulator registers that hold real channels
+            unsigned short pre[16];
+            {
+                const uint16_t* src = (MODE == MODE_DECODE) ? A.msb : A.img;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pre[r] = 0;
+                    if (r < nreg) pre[r] = src[(int64_t)min(acc_row(r, h), C - 1) * HW + pix];
+                }
+            }
             f32x16 acc[NT];
             f32x16 hid[NT];
             // ---- layer 0: C operand = bias, then k = 0..F-1 in order
@@ -302,10 +355,12 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                     for (int tt = 0; tt < NT; ++tt)
                         acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][tt], bq[u], acc[tt], 0, 0, 0);
             }
+            ASTAMP(1);  // layer 0
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) hid[tt][r] = siren_act(acc[tt][r]);
+            ASTAMP(2);  // sin
             // ---- hidden layers 1..nl-1: B operand = previous activations, straight from registers
             for (int l = 1; l < A.net.nl; ++l) {
                 const float* wlayer = wh + (size_t)(l - 1) * half * 64 * NT;
@@ -331,6 +386,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) hid[tt][r] = siren_act(acc[tt][r]);
             }
+            ASTAMP(3);  // hidden layers incl. their sin
             // ---- last layer: rows = channels
             f32x16 o;
 #pragma unroll
@@ -344,29 +400,32 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                 float a = wl[s * 64 + lane];
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, o, 0, 0, 0);
             }
+            ASTAMP(4);  // last layer
             // ---- epilogue
-            const int yy = y0 + ly, xx = x0 + lx + j;
-            const bool inside = yy < g.H && xx < g.W;
-            const int64_t pix = (int64_t)yy * g.W + xx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ch = acc_row(r, h);
-                if (ch < C && inside) {
+                if (r < nreg && ch < C && inside) {
                     float yv = canon_sigmoid(o[r]);
                     if (MODE == MODE_DECODE) {
                         float rr = __builtin_rintf(yv * scale);  // torch.round, decode.py:131
-                        int base = (int)A.msb[(int64_t)ch * HW + pix] << g.K;  // decode.py:134
+                        int base = (int)pre[r] << g.K;             // decode.py:134
                         A.out[(int64_t)ch * HW + pix] = (uint16_t)(base + (int)rr);
                         if (A.y_out) A.y_out[pix * C + ch] = yv;
                     } else {
-                        float lab = (float)((int)A.img[(int64_t)ch * HW + pix] & lmask) / scale;
+                        float lab = (float)((int)pre[r] & lmask) / scale;
                         float d = yv - lab;
                         sse += (double)(d * d);
                     }
                 }
             }
+            ASTAMP(5);  // epilogue
         }
     }
+#ifdef LBDRN_APPLY_STAMPS
+    if (tid == 0 && A.stamps)
+        for (int k = 0; k < 8; ++k) A.stamps[(size_t)blockIdx.x * 8 + k] = acc_t[k];
+#endif
     if (MODE == MODE_EVAL) {
         __syncthreads();
         double* red = reinterpret_cast<double*>(lds);  // weights no longer needed
@@ -419,10 +478,12 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
     LBDRN_LAUNCH_CHECK();
     A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
     A.partial = partial;
-    {
-        static const int stagger = [] { const char* e = getenv("LBDRN_APPLY_STAGGER"); return e ? atoi(e) : 0; }();
-        A.stagger = stagger;
-    }
+    A.stamps = nullptr;
+#ifdef LBDRN_APPLY_STAMPS
+    static unsigned long long* stamp_buf = nullptr;
+    if (!stamp_buf) LBDRN_HIP_TRY(hipMalloc(&stamp_buf, 1024 * 8 * sizeof(unsigned long long)));
+    A.stamps = stamp_buf;
+#endif
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -440,6 +501,18 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
         k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, grid, sse);
         LBDRN_LAUNCH_CHECK();
     }
+#ifdef LBDRN_APPLY_STAMPS
+    if (rc == 0) {
+        LBDRN_HIP_TRY(hipStreamSynchronize(s));
+        unsigned long long h[1024 * 8];
+        LBDRN_HIP_TRY(hipMemcpy(h, A.stamps, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum[8] = {};
+        for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)h[b * 8 + k];
+        const double blocks = (double)A.p.tiles_x * A.p.tiles_y * A.p.TH * (TILE_W / 32) / APPLY_WAVES / grid;
+        fprintf(stderr, "[lbdrn apply stamps] per wave: tiles-staging %.0f total; per 32-px block: L0 %.0f sin %.0f hidden %.0f last %.0f epilogue %.0f\n",
+                sum[0] / grid, sum[1] / grid / blocks, sum[2] / grid / blocks, sum[3] / grid / blocks, sum[4] / grid / blocks, sum[5] / grid / blocks);
+    }
+#endif
     return rc;
 }
 

@@ -47,7 +47,7 @@ def build(force=False, extra=(), out=None):
 
 if __name__ == "__main__":
     if "--stamps" in sys.argv:  # diagnostic build with in-kernel s_memtime stamps (never benchmarked)
-        print(build(force=True, extra=["-DLBDRN_TRAIN_STAMPS"],
+        print(build(force=True, extra=["-DLBDRN_TRAIN_STAMPS", "-DLBDRN_APPLY_STAMPS"],
                     out=os.path.join(os.path.dirname(HERE), "liblbdrn_hip_stamps.so")))
     else:
         print(build(force="--force" in sys.argv))

@@ -18,4 +18,4 @@ for _ in range(3): ops.eval_sse(geom, net, img_d, msb_d, p, ws=ws)
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(10): s = ops.eval_sse(geom, net, img_d, msb_d, p, ws=ws)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
-print(f"stagger={os.environ.get('LBDRN_APPLY_STAGGER','0')}: eval pass {dt*1e3:.3f} ms -> {34816*2048*2048/dt/1e12:.1f} TFLOP/s  sse={float(s.item()):.6f}")
+print(f"eval pass {dt*1e3:.3f} ms -> {34816*2048*2048/dt/1e12:.1f} TFLOP/s  sse={float(s.item()):.6f}")
