@@ -44,15 +44,22 @@ def parse():
     p.add_argument("-e", "--epochs", type=int, default=10)
     p.add_argument("--lr", type=float, default=1e-3)
     p.add_argument("--path", choices=["auto", "generic", "mfma"], default="auto")
+    p.add_argument("--coords-embedding", action="store_true",
+                   help="BASELINE.json configs[4]: USE_COORDINATES=True + EMBEDDING=True (F = 250)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=192, help="side of the CPU-baseline crop")
     return p.parse_args()
 
 
+def feat_cfg(a):
+    from lbdrn_hip.features import FeatCfg
+    return FeatCfg(use_coordinates=a.coords_embedding, embedding=a.coords_embedding)
+
+
 def one_image(codec, ops, img_d, a, path):
     """encode (fit) + weight truncation + decode (apply) for one HBM-resident tile."""
     torch.manual_seed(SEED)  # every encode.py invocation seeds itself (ref encode.py:200-205)
-    fit = codec.fit_device(img_d, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, path=path)
+    fit = codec.fit_device(img_d, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=feat_cfg(a), path=path)
     params = codec.truncate_device(fit.best_params, 16)
     rec = codec.apply_device(fit.geom, fit.net, fit.msb, params, path=path)
     return fit, rec
@@ -122,7 +129,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
                 "apply_pass_ms": round(t_eval, 3), "apply_tflops": round(fwd * N / (t_eval * 1e-3) / 1e12, 3),
                 "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1)})
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")   # committed rocprofv3 --pmc summary, if any
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and out["kernel"].startswith("k_train_mfma"):
         try:
             d = json.load(open(pmc))
             out["traffic"] = d.get("k_train_mfma_hbm_bytes_per_launch")
@@ -133,26 +140,34 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
 
 
 def cpu_baseline(a):
-    """The torch-CPU restatement of the reference loop (oracle/torch_port.py, form A: map-style
-    dataset + DataLoader + per-step update + concatenating whole-image metric) on a crop of the same
-    synthetic tile, sized for ~10-30 s."""
+    """The torch-CPU restatement of the reference loop (oracle/torch_port.py) on a crop of the same
+    synthetic tile, sized for ~10-30 s.  Form A (the headline): map-style dataset + DataLoader + per-step
+    update + concatenating whole-image metric, i.e. the reference's cost structure; form B beside it:
+    index_select minibatches + streaming MSE (math only).  GDAL / fpzip / file I/O excluded from both."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
     import torch_port as TP
     from lbdrn_hip.synth import synthetic_tile
     side = a.cpu_sample
     img = synthetic_tile(0, a.bands, a.height, a.width)[:, :side, :side].copy()
-    torch.manual_seed(SEED)
-    t0 = time.time()
-    r = TP.fit(img, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, faithful=True)
-    t_enc = time.time() - t0
-    t0 = time.time()
-    TP.apply(r["msb"], r["params"], a.K, a.D, a.bc, a.nl)
-    t_dec = time.time() - t0
-    return {"value": round(side * side / (t_enc + t_dec) / 1e6, 6), "unit": "Mpixels/s",
-            "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{side}x{side}x{a.bands} crop of tile 0, full recipe (e={a.epochs}, bs={a.bs}), "
-                      f"DataLoader(num_workers=0) + per-step Adam + concatenating eval metric; "
-                      f"encode {t_enc:.1f}s decode {t_dec:.1f}s; feature build excluded from neither"}
+    ocfg = O.FeatCfg(use_coordinates=a.coords_embedding, embedding=a.coords_embedding)
+    out = {}
+    for form, faithful in (("A", True), ("B", False)):
+        torch.manual_seed(SEED)
+        t0 = time.time()
+        r = TP.fit(img, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=ocfg, faithful=faithful)
+        t_enc = time.time() - t0
+        t0 = time.time()
+        TP.apply(r["msb"], r["params"], a.K, a.D, a.bc, a.nl, cfg=ocfg)
+        t_dec = time.time() - t0
+        out[form] = (side * side / (t_enc + t_dec) / 1e6, t_enc, t_dec)
+    return {"value": round(out["A"][0], 6), "unit": "Mpixels/s", "cores": torch.get_num_threads(),
+            "host_cpus": os.cpu_count(), "kind": "port",
+            "vectorised_form_B": round(out["B"][0], 6),
+            "sample": f"{side}x{side}x{a.bands} crop of tile 0, full recipe (e={a.epochs}, bs={a.bs}); form A = "
+                      f"DataLoader(num_workers=0) + per-step Adam + concatenating eval metric: encode "
+                      f"{out['A'][1]:.1f}s decode {out['A'][2]:.1f}s; form B = index_select batches + streaming MSE: "
+                      f"encode {out['B'][1]:.1f}s decode {out['B'][2]:.1f}s"}
 
 
 def main():
@@ -212,8 +227,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {a.bands}-band {a.height}x{a.width} uint16 tile per step, "
-                                   f"K={a.K} D={a.D} bc={a.bc} nl={a.nl} bs={a.bs} e={a.epochs} "
-                                   f"(BASELINE.json configs[1]); encode fit + 16-bit weight truncation + decode",
+                                   f"K={a.K} D={a.D} bc={a.bc} nl={a.nl} bs={a.bs} e={a.epochs}"
+                                   f"{' USE_COORDINATES+EMBEDDING' if a.coords_embedding else ''} "
+                                   f"(BASELINE.json configs[1] by default); encode fit + 16-bit weight truncation + decode",
                        "tiles_per_gpu": a.steps, "parallelism": f"image-sharded x{world}", "path": a.path},
             "recon_mse_last_tile": round(mse, 4),
             "recon_psnr_last_tile": round(10 * np.log10(10000 ** 2 / max(mse, 1e-12)), 3),

@@ -1,5 +1,5 @@
 // Generic (any-shape) HIP kernels of the LBDRN hot path: bit split, label / feature matrices,
-// a k-ordered tiled f32 GEMM with fused epilogues for forward / backward, loss, Adam, whole-image
+// a k-ordered MFMA-tiled f32 GEMM with fused epilogues for forward / backward, loss, Adam, whole-image
 // squared error and integer reconstruction.  These serve every configuration the reference
 // accepts (any bc, nl, C, D, constants.py switches); the fused MFMA kernels in apply_mfma.hip /
 // train_mfma.hip take over for the shapes they support and must reproduce these bit for bit
@@ -158,22 +158,35 @@ int generic_features(const lbdrn_geom& g, const uint16_t* msb, const int64_t* id
 
 // ------------------------------------------------------------------ tiled k-ordered GEMM
 
-// C[m][n] = store( init(m,n) + sum_k a(m,k)*b(k,n) ), k ascending, one fmaf per term.
-// 64x64 output tile per 256-thread block, 4x4 outputs per thread, BK = 16.
+// C[m][n] = store( init(m,n) + sum_k a(m,k)*b(k,n) ), k ascending, one fma per term -- on the matrix
+// cores: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain seeded by its C operand, so tiling the sum
+// over MFMA steps of four consecutive k keeps exactly the order of a scalar loop (and of the oracle).
+// 64x64 output tile per 256-thread block: wave (wm, wn) owns a 32x32 quarter as 2x2 MFMA tiles; BK = 16
+// (four MFMA steps).  Both operand tiles sit in LDS as [row][16 k] with the k positions interleaved by
+// quarter (slot (k%4)*4 + k/4): lane quarter q needs k = 4s+q for the steps s = 0..3 of a k-tile, which
+// are then 16 contiguous bytes -- one ds_read_b128 per operand tile per k-tile.  Row pitch 20 floats (an
+// odd number of 16-byte chunks).  This is the MFMA-tiled GEMM path of every shape the fused kernels do
+// not cover (bc = 256, nl > 3, C > 16 ...).
+typedef float gemm_f32x4 __attribute__((ext_vector_type(4)));
+
 template <class Prob>
-__global__ void __launch_bounds__(256) k_gemm64(Prob p)
+__global__ void __launch_bounds__(256) k_gemm_mfma(Prob p)
 {
-    constexpr int BM = 64, BN = 64, BK = 16, PAD = 4;
-    __shared__ float As[BK][BM + PAD];
-    __shared__ float Bs[BK][BN + PAD];
-    const int tid = threadIdx.x;
-    const int ty = tid >> 4, tx = tid & 15;
+    constexpr int BM = 64, BN = 64, BK = 16, PITCH = 20;
+    __shared__ __attribute__((aligned(16))) float As[BM * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int i = lane & 15, q = lane >> 4;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    float acc[4][4];
+    gemm_f32x4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = p.init(m0 + ty * 4 + i, n0 + tx * 4 + j);
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[mt][nt][r] = p.init(m0 + 32 * wm + 16 * mt + 4 * q + r, n0 + 32 * wn + 16 * nt + i);
     // optional split over k (blockIdx.z): slices of p.kchunk terms, each k-ordered
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.Kd, kbeg + p.kchunk);
@@ -181,34 +194,41 @@ __global__ void __launch_bounds__(256) k_gemm64(Prob p)
         const int kmax = min(BK, kend - k0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            int e = tid + r * 256;
+            const int e = tid + r * 256;
             int kk, mm;
             if (Prob::a_k_contig) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
-            As[kk][mm] = (kk < kmax && m0 + mm < p.M) ? p.a(m0 + mm, k0 + kk) : 0.0f;
+            As[mm * PITCH + (kk & 3) * 4 + (kk >> 2)] = (kk < kmax && m0 + mm < p.M) ? p.a(m0 + mm, k0 + kk) : 0.0f;
             int kb, nn;
             if (Prob::b_k_contig) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
-            Bs[kb][nn] = (kb < kmax && n0 + nn < p.N) ? p.b(k0 + kb, n0 + nn) : 0.0f;
+            Bs[nn * PITCH + (kb & 3) * 4 + (kb >> 2)] = (kb < kmax && n0 + nn < p.N) ? p.b(k0 + kb, n0 + nn) : 0.0f;
         }
         __syncthreads();
-        for (int kk = 0; kk < kmax; ++kk) {
-            float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
-            float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
-            const float a[4] = {av.x, av.y, av.z, av.w};
-            const float b[4] = {bv.x, bv.y, bv.z, bv.w};
+        float4 a4[2], b4[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma_(a[i], b[j], acc[i][j]);
+        for (int t = 0; t < 2; ++t) {
+            a4[t] = *reinterpret_cast<const float4*>(&As[(32 * wm + 16 * t + i) * PITCH + 4 * q]);
+            b4[t] = *reinterpret_cast<const float4*>(&Bs[(32 * wn + 16 * t + i) * PITCH + 4 * q]);
         }
+        const float av[2][4] = {{a4[0].x, a4[0].y, a4[0].z, a4[0].w}, {a4[1].x, a4[1].y, a4[1].z, a4[1].w}};
+        const float bv[2][4] = {{b4[0].x, b4[0].y, b4[0].z, b4[0].w}, {b4[1].x, b4[1].y, b4[1].z, b4[1].w}};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)  // k = k0 + 4*s4 + q: ascending over steps, ascending within a step
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt][s4], bv[nt][s4], acc[mt][nt], 0, 0, 0);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < p.M && n < p.N) p.store(m, n, acc[i][j], (int)blockIdx.z);
-        }
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 32 * wm + 16 * mt + 4 * q + r, n = n0 + 32 * wn + 16 * nt + i;
+                if (m < p.M && n < p.N) p.store(m, n, acc[mt][nt][r], (int)blockIdx.z);
+            }
 }
 
 template <class Prob>
@@ -216,7 +236,7 @@ static int launch_gemm(const Prob& p, hipStream_t s)
 {
     if (p.M <= 0 || p.N <= 0) return 0;
     dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, (p.Kd + p.kchunk - 1) / p.kchunk);
-    k_gemm64<Prob><<<grid, 256, 0, s>>>(p);
+    k_gemm_mfma<Prob><<<grid, 256, 0, s>>>(p);
     LBDRN_LAUNCH_CHECK();
     return 0;
 }

@@ -192,7 +192,8 @@ def test_train_steps_match_reference_fixture(golden, dev):
     np.testing.assert_allclose(v.cpu().numpy(), T["exp_avg_sq"], rtol=0, atol=1e-5 * np.abs(T["exp_avg_sq"]).max())
 
 
-@pytest.mark.parametrize("F,bc,C,nl,B", [(200, 64, 8, 2, 300), (18, 16, 3, 3, 64), (27, 32, 3, 1, 1000)])
+@pytest.mark.parametrize("F,bc,C,nl,B", [(200, 64, 8, 2, 300), (18, 16, 3, 3, 64), (27, 32, 3, 1, 1000),
+                                         (200, 256, 8, 2, 257)])  # last: BASELINE config 3 shape
 def test_train_step_vs_oracle(dev, F, bc, C, nl, B):
     rng = np.random.default_rng(B + F)
     p0 = _rand_params(rng, F, bc, C, nl)
