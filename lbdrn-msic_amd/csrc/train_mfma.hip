@@ -363,6 +363,10 @@ struct WtBuf {  // buffer descriptor of a wave-uniform region + 16-byte write-th
     {
         r = __builtin_amdgcn_make_buffer_rsrc(p, (short)0, (int)bytes, 0x00020000);
     }
+    __device__ __forceinline__ void store_plain(int float_off, float a, float b, float c, float d) const
+    {
+        *reinterpret_cast<float4*>(base + float_off) = make_float4(a, b, c, d);
+    }
     __device__ __forceinline__ void store(int float_off, float a, float b, float c, float d) const
     {
 #ifdef LBDRN_PLAIN_SLAB_STORES
@@ -427,6 +431,16 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     int64_t mypix = 0;
     if (!staged && tid < TB) mypix = A.perm[first + min(tid, nvalid - 1)];
     const int rs = tid >> 4, rsub = tid & 15;  // row copy: 16 threads per row
+    constexpr int NLD = (XP / 4 + 15) / 16;
+    const int rp4 = p.RP >> 2;
+    // the staged rows are what the first barrier waits for: request them before the (TA-bound, ~5 k cycle)
+    // weight prefetch so that they arrive while it is still being issued
+    float4 v[NLD];
+    if (staged) {
+        const float* src = A.stage_in + ((size_t)wg * TB + rs) * p.RP;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) v[u] = *reinterpret_cast<const float4*>(src + 4 * min(rsub + 16 * u, rp4 - 1));
+    }
     int64_t nextpix = -1;
     // (rows past the end of a short minibatch repeat its last row, like the direct gather does: they
     //  are masked out of the loss but must hold finite values)
@@ -494,19 +508,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     // ---- phase 1: copy the 32 rows (features | labels) into LDS, row-major (X) and transposed (XT):
     //      16 threads per row, 16 B per load, all loads issued before the first store
     //      (a4: ref LBDRNdataset.py:151-155)
-    constexpr int NLD = (XP / 4 + 15) / 16;
-    const int rp4 = p.RP >> 2;
     float4 vnext[NLD];
     {
         const int s = rs, sub = rsub;
-        const float* src = staged ? A.stage_in + ((size_t)wg * TB + s) * p.RP : A.rows + (size_t)pixs[s] * p.RP;
         float* xr = Xs + s * XP;
         const int nt16 = 16 * p.NT0;
-        float4 v[NLD];
+        if (!staged) {  // first step of an epoch: gather for itself
+            const float* src = A.rows + (size_t)pixs[s] * p.RP;
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            int c4 = min(sub + 16 * u, rp4 - 1);  // clamped: never a load behind a branch
-            v[u] = *reinterpret_cast<const float4*>(src + 4 * c4);
+            for (int u = 0; u < NLD; ++u) v[u] = *reinterpret_cast<const float4*>(src + 4 * min(sub + 16 * u, rp4 - 1));
         }
         // the next minibatch's rows: issued now, consumed at the very end of the kernel
         {
@@ -606,6 +616,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     __syncthreads();
     if (tid == 0) A.loss_part[wg] = red[0] + red[1];
     STAMP(6);
+    // (the loads were issued ~8 k cycles ago; storing here, write-through, lets them drain under the backward pass)
+    if (nextpix >= 0) {  // park the next minibatch's rows (loaded at kernel start) in the staging buffer
+        const WtBuf stw(A.stage_out + (size_t)wg * TB * p.RP, (size_t)TB * p.RP * 4);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int c4 = rsub + 16 * u;
+            if (c4 < rp4) stw.store(rs * p.RP + 4 * c4, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
+        }
+    }
 
     auto backprop_store = [&](int l) {  // acc = dL/dh_l  ->  dz_l = (dh * cos(30 z)) * 30
         float dz[4];
@@ -645,7 +664,9 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     // ---- phase 7: weight gradients, K = 32 samples (8 MFMA steps, quarter q walks samples 8q..8q+7):
     //      dW[16w + row][16nt + col] = sum_s dz[s][16w + row] * in[s][16nt + col]; wave (w, st) takes the
     //      column tiles nt = st, st+2, ...; each finished tile leaves as one 1 KB store in tile order.
-    auto grad_tiles = [&](const float* zt, const float* bt, int ntiles, int out) {
+    // early = written through (drains under the remaining phases); late tiles use plain stores: a write-
+    // through store issued just before the kernel ends only adds its full latency to the tail
+    auto grad_tiles = [&](const float* zt, const float* bt, int ntiles, int out, bool early) {
         float az[8];
         lds_load<8>(zt + (16 * w + i) * TP + 8 * q, az);
         for (int nt = st; nt < ntiles; nt += 4) {
@@ -661,15 +682,20 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
                 g0 = MFMA16(az[s], b0[s], g0);
                 g1 = MFMA16(az[s], b1[s], g1);
             }
-            slabw.store(out + ((w * ntiles + nt) * 64 + lane) * 4, g0[0], g0[1], g0[2], g0[3]);
-            if (two) slabw.store(out + ((w * ntiles + nt1) * 64 + lane) * 4, g1[0], g1[1], g1[2], g1[3]);
+            if (early) {
+                slabw.store(out + ((w * ntiles + nt) * 64 + lane) * 4, g0[0], g0[1], g0[2], g0[3]);
+                if (two) slabw.store(out + ((w * ntiles + nt1) * 64 + lane) * 4, g1[0], g1[1], g1[2], g1[3]);
+            } else {
+                slabw.store_plain(out + ((w * ntiles + nt) * 64 + lane) * 4, g0[0], g0[1], g0[2], g0[3]);
+                if (two) slabw.store_plain(out + ((w * ntiles + nt1) * 64 + lane) * 4, g1[0], g1[1], g1[2], g1[3]);
+            }
         }
     };
-    grad_tiles(ZT, XT, p.NT0, 0);
+    grad_tiles(ZT, XT, p.NT0, 0, true);
     STAMP(10);
 #pragma unroll
     for (int l = 1; l < NL; ++l)
-        grad_tiles(ZT + (size_t)l * TBC * TP, HT + (size_t)(l - 1) * TBC * TP, 4, p.sl_hid + (l - 1) * 16 * 256);
+        grad_tiles(ZT + (size_t)l * TBC * TP, HT + (size_t)(l - 1) * TBC * TP, 4, p.sl_hid + (l - 1) * 16 * 256, false);
     if (st == 0) {  // output layer: rows = channel slots, wave w takes hidden columns 16w..16w+15
         float az[8], bv[8];
         lds_load<8>(ZoT + i * TP + 8 * q, az);
@@ -681,7 +707,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
             g0 = MFMA16(az[s], bv[s], g0);
             g1 = MFMA16(az[s + 1], bv[s + 1], g1);
         }
-        slabw.store(p.sl_out + (w * 64 + lane) * 4, g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]);
+        slabw.store_plain(p.sl_out + (w * 64 + lane) * 4, g0[0] + g1[0], g0[1] + g1[1], g0[2] + g1[2], g0[3] + g1[3]);
     }
     STAMP(11);
     // bias gradients: sums over the 32 samples of one unit = one row of the transposed copies
@@ -694,14 +720,6 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
         slab[p.sl_bias + u] = v;
     }
     for (int u = p.sl_bias + NL * TBC + 16 + tid; u < p.slab_floats; u += TRAIN_THREADS) slab[u] = 0.0f;
-    if (nextpix >= 0) {  // park the next minibatch's rows (loaded at kernel start) in the staging buffer
-        const WtBuf stw(A.stage_out + (size_t)wg * TB * p.RP, (size_t)TB * p.RP * 4);
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int c4 = rsub + 16 * u;
-            if (c4 < rp4) stw.store(rs * p.RP + 4 * c4, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
-        }
-    }
     STAMP(8);
 #ifdef LBDRN_TRAIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
