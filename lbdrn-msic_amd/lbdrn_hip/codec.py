@@ -12,7 +12,7 @@ import torch
 from . import ops
 from .features import FeatCfg
 from .model import LBDRNModel
-from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, PermutationStream
+from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX
 
 
 def lr_schedule(lr, epochs):
@@ -78,8 +78,11 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     params = model.flat_parameters().to(dev).contiguous()
     exp_avg = torch.zeros_like(params)
     exp_avg_sq = torch.zeros_like(params)
-    stream = (DevicePermutationStream(N, epochs, val_duration, dev) if N < GPU_RANDPERM_MAX
-              else PermutationStream(N, epochs, val_duration, workers=perm_workers))
+    if N >= GPU_RANDPERM_MAX:
+        raise ops._lib.LbdrnError(
+            f"{N} pixels in one fit: torch.randperm switches algorithm at 2^32/20 elements and lbdrn_randperm "
+            "implements the Fisher-Yates branch only; split the image (-sr) -- there is no host fallback")
+    stream = DevicePermutationStream(N, epochs, val_duration, dev)
     lrs = lr_schedule(lr, epochs)
     steps_per_epoch = (N + batch_size - 1) // batch_size
     losses = torch.zeros((epochs, steps_per_epoch), dtype=torch.float32, device=dev) if keep_losses else None

@@ -93,7 +93,10 @@ GPU_RANDPERM_MAX = 0xFFFFFFFF // 20  # torch's randperm switches algorithm above
 
 
 class PermutationStream:
-    """Draws every pass's seed up front (the global generator is touched by nothing else during the
+    """Host-side twin of DevicePermutationStream (torch.randperm on worker threads).  Not used by the fit:
+    it is the form the CPU tests compare with a real DataLoader, and what the GPU stream is checked against.
+
+    Draws every pass's seed up front (the global generator is touched by nothing else during the
     fit) and computes the train permutations on worker threads so that the host-side Fisher-Yates
     (0.1-0.3 s for 4 M indices) overlaps the GPU work of earlier epochs."""
 
