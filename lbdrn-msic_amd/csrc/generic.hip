@@ -190,19 +190,39 @@ __global__ void __launch_bounds__(256) k_gemm_mfma(Prob p)
     // optional split over k (blockIdx.z): slices of p.kchunk terms, each k-ordered
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.Kd, kbeg + p.kchunk);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // operand tiles go global -> registers -> LDS; the registers of k-tile t+1 are loaded while the MFMAs of
+    // k-tile t run (the loads are issued before the MFMAs and written to LDS after the second barrier)
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
         const int kmax = min(BK, kend - k0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = tid + r * 256;
             int kk, mm;
             if (Prob::a_k_contig) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
-            As[mm * PITCH + (kk & 3) * 4 + (kk >> 2)] = (kk < kmax && m0 + mm < p.M) ? p.a(m0 + mm, k0 + kk) : 0.0f;
+            ra[r] = (kk < kmax && m0 + mm < p.M) ? p.a(m0 + mm, k0 + kk) : 0.0f;
             int kb, nn;
             if (Prob::b_k_contig) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
-            Bs[nn * PITCH + (kb & 3) * 4 + (kb >> 2)] = (kb < kmax && n0 + nn < p.N) ? p.b(k0 + kb, n0 + nn) : 0.0f;
+            rb[r] = (kb < kmax && n0 + nn < p.N) ? p.b(k0 + kb, n0 + nn) : 0.0f;
         }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = tid + r * 256;
+            int kk, mm;
+            if (Prob::a_k_contig) { kk = e & 15; mm = e >> 4; } else { mm = e & 63; kk = e >> 6; }
+            As[mm * PITCH + (kk & 3) * 4 + (kk >> 2)] = ra[r];
+            int kb, nn;
+            if (Prob::b_k_contig) { kb = e & 15; nn = e >> 4; } else { nn = e & 63; kb = e >> 6; }
+            Bs[nn * PITCH + (kb & 3) * 4 + (kb >> 2)] = rb[r];
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        park();
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
         float4 a4[2], b4[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
