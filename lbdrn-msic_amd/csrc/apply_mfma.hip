@@ -258,7 +258,8 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             // element: 27 % of the kernel).  Index split by multiply-high (exact for e < 2^16, SW,SH < 2^8).
             const int plane = p.SH * p.SW, total = C * plane;
             const unsigned msw = 0xFFFFFFFFu / (unsigned)p.SW + 1u, msh = 0xFFFFFFFFu / (unsigned)p.SH + 1u;
-            const bool simple = D < g.H && D < g.W && total < 65536;
+            // (SH == 1 would need the multiplier 2^32: such single-row tiles take the dividing path)
+            const bool simple = D < g.H && D < g.W && total < 65536 && p.SH > 1;
             constexpr int UB = 8;
             for (int base = 0; base < total; base += APPLY_THREADS * UB) {
                 unsigned short raw[UB];

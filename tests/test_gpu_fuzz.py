@@ -1,0 +1,131 @@
+"""Randomised shapes: the fused MFMA kernels against the generic kernels (bit-exact for apply, training
+tolerance for the step) and, on a subsample, against the oracle.  Seeds are fixed: the cases are the same
+every run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from lbdrn_hip import ops
+from lbdrn_hip.features import FeatCfg
+
+pytestmark = pytest.mark.gpu
+GEN, MFMA = ops._lib.PATH_GENERIC, ops._lib.PATH_MFMA
+SOAK = int(os.environ.get("LBDRN_FUZZ_SOAK", "1"))   # multiply the case count for a longer soak
+
+
+def _params(rng, F, bc, C, nl, gain):
+    parts = []
+    for l in range(nl):
+        nin = F if l == 0 else bc
+        b = (1.0 / nin if l == 0 else np.sqrt(6.0 / nin) / 30.0) * gain
+        parts += [rng.uniform(-b, b, bc * nin), rng.uniform(-b, b, bc)]
+    b = np.sqrt(6.0 / bc) / 30.0 * gain
+    parts += [rng.uniform(-b, b, C * bc), rng.uniform(-b, b, C)]
+    return np.concatenate(parts).astype(np.float32)
+
+
+def _random_case(rng, train):
+    C = int(rng.integers(1, 17 if train else 33))
+    D = int(rng.integers(0, 4))
+    K = int(rng.integers(1, 9))
+    H = int(rng.integers(max(2, D + 1), 70))
+    W = int(rng.integers(max(2, D + 1), 150))
+    coords = bool(rng.integers(0, 2))
+    embed = coords and bool(rng.integers(0, 2))
+    colors = True if not coords else bool(rng.integers(0, 4) > 0)
+    rel = bool(rng.integers(0, 2))
+    bc = 64 if train else int(rng.choice([32, 64, 128]))
+    nl = int(rng.integers(1, 4))
+    cfg = FeatCfg(coords, embed, 1.4, 12, colors, rel)
+    hi = int(rng.choice([255, 4000, 10000, 65535]))
+    img = rng.integers(0, hi + 1, (C, H, W)).astype(np.uint16)
+    return C, H, W, K, D, bc, nl, cfg, img
+
+
+def test_apply_fuzz_mfma_equals_generic_and_oracle(dev):
+    rng = np.random.default_rng(20240101)
+    checked_oracle = 0
+    ran = 0
+    for it in range(24 * SOAK):
+        C, H, W, K, D, bc, nl, cfg, img = _random_case(rng, train=False)
+        F = cfg.feature_dim(C, D)
+        if F > 400:
+            continue
+        msb = img >> K
+        mx = int(msb.max())
+        if mx == 0:
+            continue
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(F, bc, C, nl)
+        p = torch.from_numpy(_params(rng, F, bc, C, nl, 2.5)).to(dev)
+        msb_d, img_d = ops.to_device_u16(msb, dev), ops.to_device_u16(img, dev)
+        try:
+            a, ya = ops.decode_fused(geom, net, msb_d, p, want_y=True, path=MFMA)
+        except ops._lib.LbdrnError:
+            continue  # shape outside the fused kernel's LDS budget
+        b, yb = ops.decode_fused(geom, net, msb_d, p, want_y=True, path=GEN)
+        tag = (it, C, H, W, K, D, bc, nl, vars(cfg))
+        assert torch.equal(a, b), tag
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), tag
+        s1 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA).item())
+        s2 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item())
+        assert abs(s1 - s2) <= 1e-11 * max(s2, 1e-30), tag
+        ran += 1
+        if H * W <= 2500 and checked_oracle < 8:
+            ocfg = O.FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative)
+            ro = O.decode(msb, K, D, ocfg, p.cpu().numpy(), bc, nl, mx)
+            assert np.array_equal(ops.from_device_u16(a), ro), tag
+            checked_oracle += 1
+    assert ran >= 10 and checked_oracle >= 3, (ran, checked_oracle)
+
+
+def test_train_fuzz_mfma_matches_generic(dev):
+    rng = np.random.default_rng(77)
+    done = 0
+    for it in range(16 * SOAK):
+        C, H, W, K, D, bc, nl, cfg, img = _random_case(rng, train=True)
+        F = cfg.feature_dim(C, D)
+        msb = img >> K
+        mx = int(msb.max())
+        if mx == 0 or F > 256:
+            continue
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(F, 64, C, nl)
+        p0 = _params(rng, F, 64, C, nl, 1.0)
+        bs = int(rng.choice([64, 100, 257, 1000]))
+        img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+        order = rng.permutation(H * W).astype(np.int64)
+        tag = (it, C, H, W, K, D, nl, bs, vars(cfg))
+
+        def run(perm_np):
+            perm = torch.from_numpy(perm_np).to(dev)
+            nsteps = (len(perm_np) + bs - 1) // bs
+            out = {}
+            for path in (MFMA, GEN):
+                p = torch.from_numpy(p0.copy()).to(dev)
+                m, v = torch.zeros_like(p), torch.zeros_like(p)
+                losses = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+                ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 0, 1e-3, losses, path=path)
+                out[path] = [t.cpu().numpy() for t in (p, losses, m, v)]
+            return out[MFMA], out[GEN], nsteps
+
+        try:
+            # one (usually ragged) step: exp_avg = 0.1 * gradient exactly, the sharp check of the backward pass
+            (pa, la, ma, va), (pb, lb, mb, vb), _ = run(order[:int(rng.integers(1, min(bs, H * W) + 1))])
+            np.testing.assert_allclose(la, lb, rtol=2e-5, err_msg=str(tag))
+            assert np.abs(ma - mb).max() <= 2e-5 * np.abs(mb).max(), tag
+            assert np.abs(va - vb).max() <= 5e-5 * np.abs(vb).max(), tag
+            # a few steps, the last one ragged.  Adam turns rounding-level differences into lr-sized ones
+            # wherever a gradient is near zero (step 1 moves every parameter by lr * g/(|g|+eps)), so
+            # parameters are compared (in rms) against the distance they can travel, not to rounding
+            (pa, la, ma, va), (pb, lb, mb, vb), nsteps = run(order[:5 * bs + int(rng.integers(1, bs + 1))])
+            np.testing.assert_allclose(la, lb, rtol=5e-5, err_msg=str(tag))
+            assert np.linalg.norm(pa - pb) <= 0.01 * 1e-3 * nsteps * np.sqrt(len(pa)), tag
+            assert np.isfinite(pa).all(), tag
+        except ops._lib.LbdrnError:
+            continue
+        done += 1
+    assert done >= 6, done
