@@ -129,3 +129,61 @@ def test_train_fuzz_mfma_matches_generic(dev):
             continue
         done += 1
     assert done >= 6, done
+
+
+def test_split_labels_features_fuzz_equal_oracle(dev):
+    rng = np.random.default_rng(5)
+    for it in range(20 * SOAK):
+        C, H, W, K, D, _, _, cfg, img = _random_case(rng, train=False)
+        if cfg.feature_dim(C, D) * H * W > 4_000_000:
+            continue
+        ocfg = O.FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative)
+        msb, lab, mx = O.split_bits(img, K)
+        tag = (it, C, H, W, K, D, vars(cfg))
+        img_d = ops.to_device_u16(img, dev)
+        msb_d, mx_d = ops.split_bits(img_d, K)
+        assert mx_d == mx and np.array_equal(ops.from_device_u16(msb_d), msb), tag
+        if mx == 0:
+            continue
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        idx = None
+        if rng.integers(0, 2):
+            idx_np = rng.integers(0, H * W, int(rng.integers(1, 300))).astype(np.int64)
+            idx = torch.from_numpy(idx_np).to(dev)
+        f = ops.features(geom, msb_d, idx).cpu().numpy()
+        l = ops.labels(img_d, K, idx).cpu().numpy()
+        fo = O.features(msb, D, ocfg, mx)
+        lo = lab
+        if idx is not None:
+            fo, lo = fo[idx_np], lo[idx_np]
+        assert np.array_equal(f.view(np.int32), fo.view(np.int32)), tag
+        assert np.array_equal(l.view(np.int32), lo.view(np.int32)), tag
+
+
+def test_forward_and_step_fuzz_any_width_equal_oracle(dev):
+    """lbdrn_forward / lbdrn_train_step take any F, bc, C, nl, B (the generic MFMA GEMM with ragged tiles
+    and split-K): forward bit-exact, the step within the training tolerance."""
+    rng = np.random.default_rng(11)
+    for it in range(16 * SOAK):
+        F = int(rng.integers(1, 300))
+        bc = int(rng.choice([1, 7, 32, 64, 65, 100, 128, 200, 256, 300]))
+        C = int(rng.integers(1, 40))
+        nl = int(rng.integers(1, 5))
+        B = int(rng.choice([1, 3, 63, 64, 65, 255, 1000, 4097]))
+        tag = (it, F, bc, C, nl, B)
+        pn = _params(rng, F, bc, C, nl, 1.5)
+        x = rng.uniform(-1, 1, (B, F)).astype(np.float32)
+        t = rng.uniform(0, 1, (B, C)).astype(np.float32)
+        net = ops.make_net(F, bc, C, nl)
+        p = torch.from_numpy(pn).to(dev)
+        xd, td = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
+        y = ops.forward(net, p, xd).cpu().numpy()
+        yo = O.forward(pn, F, bc, C, nl, x)
+        assert np.array_equal(y.view(np.int32), yo.view(np.int32)), tag
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        loss, g = ops.train_step(net, xd, td, p, m, v, 1, 1e-3)
+        po, mo, vo = pn.copy(), np.zeros_like(pn), np.zeros_like(pn)
+        lo, go = O.train_step(po, mo, vo, F, bc, C, nl, x, t, 1e-3, 1)
+        assert abs(float(loss.item()) - lo) <= 1e-5 * abs(lo), tag
+        assert np.abs(g.cpu().numpy() - go).max() <= 2e-5 * np.abs(go).max() + 1e-12, tag
+        assert np.abs(m.cpu().numpy() - mo).max() <= 2e-5 * np.abs(mo).max() + 1e-12, tag
