@@ -299,13 +299,6 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
         __syncthreads();
 
         ASTAMP(0);  // staging + barriers
-#ifdef LBDRN_APPLY_STAGGER
-        {
-            const int wv = __builtin_amdgcn_readfirstlane(wave);
-            const bool late = (LBDRN_APPLY_STAGGER == 1) ? (wv >= 4) : (wv & 1);
-            if (late) __builtin_amdgcn_s_sleep(LBDRN_APPLY_STAGGER_N);
-        }
-#endif
         const int nseg = p.TH * (TILE_W / 32);
         for (int seg = wave; seg < nseg; seg += APPLY_WAVES) {
             const int ly = seg / (TILE_W / 32), lx = (seg % (TILE_W / 32)) * 32;

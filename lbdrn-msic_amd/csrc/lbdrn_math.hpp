@@ -59,7 +59,9 @@ LBDRN_DEV void reduce_pio2(float x, float& r, int& q)
     r = fma_(-k, kPio2B, r);
     r = fma_(-k, kPio2C, r);
     float qf = fma_(-4.0f, __builtin_floorf(k * 0.25f), k);
-    q = (qf >= 0.0f && qf < 4.0f) ? (int)qf : 0;
+    // qf is 0, 1, 2 or 3 for finite k and NaN otherwise; v_cvt_i32_f32 maps NaN to 0, which is the
+    // oracle's explicit "NaN -> 0" (four VALU instructions fewer per activation than spelling the guard)
+    asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(q) : "v"(qf));
 }
 
 LBDRN_DEV float canon_sin(float x)

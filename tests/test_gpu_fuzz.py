@@ -187,3 +187,30 @@ def test_forward_and_step_fuzz_any_width_equal_oracle(dev):
         assert abs(float(loss.item()) - lo) <= 1e-5 * abs(lo), tag
         assert np.abs(g.cpu().numpy() - go).max() <= 2e-5 * np.abs(go).max() + 1e-12, tag
         assert np.abs(m.cpu().numpy() - mo).max() <= 2e-5 * np.abs(mo).max() + 1e-12, tag
+
+
+def test_activation_special_values_equal_oracle(dev):
+    """sin(30 z) and the sigmoid for huge, infinite and NaN pre-activations: y = sigmoid(sin(30 x)) through a
+    one-feature network with unit weights, compared bit for bit (NaNs as NaNs)."""
+    rng = np.random.default_rng(3)
+    F, bc, C, nl = 1, 32, 1, 1
+    pn = np.zeros(O.param_count(F, bc, C, nl), np.float32)
+    pn[0] = 1.0                      # W0[0,0]: z_0 = x
+    pn[bc * F + bc + 0] = 1.0        # W1[0,0]: out = h_0
+    special = np.array([0.0, -0.0, 1e-30, -1e-30, 0.5, 1e3, -1e3, 1e6, 7e7, 2.5e9, -2.5e9, 1e20, 3e38, -3e38,
+                        np.inf, -np.inf, np.nan], np.float32)
+    wide = (rng.choice([-1, 1], 4000) * np.exp(rng.uniform(np.log(1e-6), np.log(3e38), 4000))).astype(np.float32)
+    x = np.concatenate([special, wide]).reshape(-1, 1)
+    net = ops.make_net(F, bc, C, nl)
+    y = ops.forward(net, torch.from_numpy(pn).to(dev), torch.from_numpy(x).to(dev)).cpu().numpy()
+    yo = O.forward(pn, F, bc, C, nl, x)
+    both_nan = np.isnan(y) & np.isnan(yo)
+    assert np.array_equal(y.view(np.int32)[~both_nan], yo.view(np.int32)[~both_nan])
+    assert np.array_equal(np.isnan(y), np.isnan(yo))
+    # the sigmoid alone: out = W1 . sin(0) + b1 = b1
+    for b1 in (0.0, -0.0, 1e-8, 20.0, -20.0, 86.5, -86.5, 200.0, -200.0, 1e30, -1e30, np.inf, -np.inf):
+        p2 = np.zeros_like(pn)
+        p2[-1] = b1
+        y = ops.forward(net, torch.from_numpy(p2).to(dev), torch.zeros(3, 1, device=dev)).cpu().numpy()
+        yo = O.forward(p2, F, bc, C, nl, np.zeros((3, 1), np.float32))
+        assert np.array_equal(y.view(np.int32), yo.view(np.int32)), b1

@@ -244,3 +244,38 @@ def test_full_size_fit_is_reproducible_and_self_consistent(dev):
     err = float(np.mean((rec.astype(np.float32) - img.astype(np.float32)) ** 2))
     base = float(np.mean(((((img >> K) << K) + 16).astype(np.float32) - img.astype(np.float32)) ** 2))
     assert err <= base * 1.02
+
+
+def test_large_tile_64bit_indexing(dev):
+    """A 4096 x 4096 x 8 tile: the row matrix (3.5 G floats) and the band planes are indexed past 2^31.
+    Minibatches drawn from the top, the bottom and all over the raster give the same losses and moments
+    on the fused path (materialised rows) and the generic path (window gather), and the fused decode of
+    the last rows equals the generic one bit for bit."""
+    C, H, W, K, D = 8, 4096, 4096, 5, 2
+    base = synthetic_tile(5, C, 1024, 1024)
+    img = np.ascontiguousarray(np.tile(base, (1, 4, 4)))
+    img[:, -1024:, -1024:] = synthetic_tile(6, C, 1024, 1024)   # the far corner differs from the rest
+    img_d = ops.to_device_u16(img, dev)
+    msb_d, mx = ops.split_bits(img_d, K)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(200, 64, C, 2)
+    rng = np.random.default_rng(8)
+    p0 = _params(rng, 200, 64, C, 2)
+    N, bs = H * W, 8192
+    perm_np = np.concatenate([np.arange(N - bs, N), np.arange(bs), rng.integers(0, N, bs)]).astype(np.int64)
+    perm = torch.from_numpy(perm_np).to(dev)
+    res = {}
+    for path in (MFMA, GEN):
+        p = torch.from_numpy(p0.copy()).to(dev)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        losses = torch.zeros(3, dtype=torch.float32, device=dev)
+        ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 0, 1e-3, losses, path=path)
+        res[path] = (losses.cpu().numpy(), m.cpu().numpy())
+    np.testing.assert_allclose(res[MFMA][0], res[GEN][0], rtol=2e-5)
+    assert np.abs(res[MFMA][1] - res[GEN][1]).max() <= 2e-4 * np.abs(res[GEN][1]).max()
+    p = torch.from_numpy(p0 * 2.0).to(dev)
+    a = ops.decode_fused(geom, net, msb_d, p, path=MFMA)
+    b = ops.decode_fused(geom, net, msb_d, p, path=GEN)
+    assert torch.equal(a, b)
+    rec = ops.from_device_u16(a[:, -64:, :])
+    assert np.array_equal(rec >> K, img[:, -64:, :] >> K)
