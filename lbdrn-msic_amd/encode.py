@@ -3,6 +3,11 @@ and log records as the reference's encode.py (ref encode.py:167-289); the per-im
 fused HIP kernels (lbdrn_hip.codec.fit_image) instead of DataLoader + ignite + autograd.
 
 Bitstream: header | for each tile (row-major): network payload | MSB payload   (ref encode.py:29-36)
+
+Multi-GPU: `python -m torch.distributed.run --nproc-per-node N encode.py ... -sr S` fits the S*S tiles of the
+image round-robin on N GPUs (one process per GPU, no exchange during the fits) and rank 0 assembles the
+.bin; the result is byte-identical to the single-GPU run because every rank replays the random draws of
+the tiles it does not fit (lbdrn_hip.codec.skip_fit_rng).
 """
 import argparse
 import os
@@ -14,7 +19,7 @@ import numpy as np
 import torch
 
 import logger
-from lbdrn_hip import codec, container, raster_io
+from lbdrn_hip import codec, container, raster_io, shard
 from lbdrn_hip.features import FeatCfg
 from LBDRNdataset import tile_windows
 
@@ -75,8 +80,17 @@ def build_parser():
     return p
 
 
-def main(argv=None):
+def main(argv=None, shard_tiles=None):
+    """shard_tiles: spread the split_ratio tiles over the ranks of a torchrun launch (default: whenever
+    WORLD_SIZE > 1; sweep.py passes False because it shards whole jobs instead)."""
+    global DEVICE
     args = build_parser().parse_args(argv)
+    rank, world = 0, 1
+    if shard_tiles is None:
+        shard_tiles = shard.env_world()[1] > 1
+    if shard_tiles:
+        rank, world, local = shard.init_host_group()
+        DEVICE = shard.device_for(local)
     if not args.randomness:
         torch.manual_seed(args.seed)
         np.random.seed(args.seed)
@@ -89,38 +103,67 @@ def main(argv=None):
     os.makedirs(args.output_dir, exist_ok=True)
     bitstream_path = f"{args.output_dir}/{filename}.bin"
     log_path = f"{args.output_dir}/encode.txt"
+    done = False
     if os.path.exists(log_path) and os.path.exists(bitstream_path):
         with open(log_path) as f:
-            if "Time elapsed" in f.read():
-                print("Bitstream already created!")
-                return 0
-    logger.create_logger(args.output_dir, "encode.txt")
+            done = "Time elapsed" in f.read()
+    if world > 1:   # one decision for all ranks, taken before anyone touches the log file
+        done = all(shard.all_to_all_objects(done))
+    if done:
+        if rank == 0:
+            print("Bitstream already created!")
+        if world > 1:
+            shard.finish()
+        return 0
+    if rank == 0:
+        logger.create_logger(args.output_dir, "encode.txt")
+    else:
+        logger.create_logger(args.output_dir, "", log_file_only=True)
     start_time = time.time()
     img = raster_io.read_raster(org_path)
     img = img.reshape((-1,) + img.shape[-2:])
     height, width = img.shape[-2:]
-    nn_payloads, base_payloads = [], []
-    if args.split_ratio > 1:
-        for i, j, x0, y0, w, h in tile_windows(width, height, args.split_ratio):
+    windows = list(tile_windows(width, height, args.split_ratio)) if args.split_ratio > 1 else [None]
+    n_feature = FeatCfg.from_constants().feature_dim(img.shape[0], args.D)
+    fitted = []   # (tile index, nn payload, MSB payload, captured log records or None)
+    for t, win in enumerate(windows):
+        tile = img
+        if win is not None:
+            i, j, x0, y0, w, h = win
             args.path = f"{args.output_dir}/tile_{i}_{j}.tif"
+            tile = np.ascontiguousarray(img[:, y0:y0 + h, x0:x0 + w])
+        if t % world != rank:
+            if not args.randomness:
+                codec.skip_fit_rng(n_feature, args.base_channel, img.shape[0], args.num_layers, args.epochs,
+                                   args.val_duration)
+            continue
+        if world > 1:
+            with logger.capture() as lines:
+                logger.log.info(args)
+                nn, base = train(args, tile)
+        else:
+            lines = None
             logger.log.info(args)
-            nn, base = train(args, np.ascontiguousarray(img[:, y0:y0 + h, x0:x0 + w]))
-            nn_payloads.append(nn)
-            base_payloads.append(base)
-    else:
-        logger.log.info(args)
-        nn, base = train(args, img)
-        nn_payloads.append(nn)
-        base_payloads.append(base)
-    header = container.pack_header(args.split_ratio, width, height, args.K, args.base_channel,
-                                   args.num_layers, args.D, [len(b) for b in nn_payloads],
-                                   [len(b) for b in base_payloads])
-    with open(bitstream_path, "wb") as f:
-        f.write(header)
-        for nn, base in zip(nn_payloads, base_payloads):
-            f.write(nn)
-            f.write(base)
-    logger.log.info(f"Time elapsed: {time.time() - start_time}")
+            nn, base = train(args, tile)
+        fitted.append((t, nn, base, lines))
+    gathered = shard.gather_to_root(fitted) if world > 1 else [fitted]
+    if rank == 0:
+        tiles = sorted((rec for part in gathered for rec in part), key=lambda rec: rec[0])
+        assert [rec[0] for rec in tiles] == list(range(len(windows)))
+        for _, _, _, lines in tiles:
+            if lines is not None:
+                logger.replay(lines)
+        header = container.pack_header(args.split_ratio, width, height, args.K, args.base_channel,
+                                       args.num_layers, args.D, [len(rec[1]) for rec in tiles],
+                                       [len(rec[2]) for rec in tiles])
+        with open(bitstream_path, "wb") as f:
+            f.write(header)
+            for _, nn, base, _ in tiles:
+                f.write(nn)
+                f.write(base)
+        logger.log.info(f"Time elapsed: {time.time() - start_time}")
+    if world > 1:
+        shard.finish()
     return 0
 
 

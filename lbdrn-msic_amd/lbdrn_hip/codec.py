@@ -12,7 +12,7 @@ import torch
 from . import ops
 from .features import FeatCfg
 from .model import LBDRNModel
-from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX
+from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, draw_iterator_seed, epoch_plan
 
 
 def lr_schedule(lr, epochs):
@@ -25,6 +25,18 @@ def lr_schedule(lr, epochs):
         if e % step == 0:
             cur *= 0.1
     return out
+
+
+def skip_fit_rng(n_feature, base_channel, channels, num_layers, epochs, val_duration=1):
+    """Consume the global torch CPU generator exactly as one fit_device() / reference train() call does
+    (model construction, then two draws per DataLoader iterator), without fitting.  The reference fits
+    the split_ratio tiles of an image one after another on ONE generator (ref encode.py:200-205, 231-262),
+    so tile t's initial weights and minibatch orders depend on how much tiles 0..t-1 drew; a rank that
+    fits only some of the tiles calls this for the ones it leaves to other ranks and so reproduces the
+    serial run bit for bit."""
+    LBDRNModel(dim_in=n_feature, dim_hidden=base_channel, dim_out=channels, num_layers=num_layers)
+    for _ in epoch_plan(epochs, val_duration):
+        draw_iterator_seed()
 
 
 class FitResult:

@@ -1,8 +1,59 @@
 """Image-level sharding for multi-GPU runs: every image (or split_ratio tile) is an
 independent fit with its own re-seeded RNG (ref encode.py:200-205), so ranks never exchange data on
-the path; the only collective is one all_gather of small per-image records at the end."""
+the path; the only collective is one all_gather of small per-image records at the end (bench.py), or
+one gather of the finished payloads to rank 0 (encode.py / decode.py / sweep.py under torchrun)."""
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def env_world():
+    """(rank, world, local_rank) as torchrun exports them; (0, 1, 0) for a plain `python` run."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def init_host_group():
+    """Process group for the CLIs' end-of-run exchange of host objects (payload bytes, log lines, tiles).
+    gloo: what is exchanged lives in host memory and no kernel waits for it; the fits themselves never
+    communicate.  Returns (rank, world, local_rank); does nothing for a single process."""
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local
+
+
+def device_for(local_rank):
+    """One process per GPU; ranks beyond the device count share devices round-robin (rehearsals on a
+    one-GPU box)."""
+    n = torch.cuda.device_count()
+    return f"cuda:{local_rank % n}" if n else "cuda:0"
+
+
+def gather_to_root(obj):
+    """Every rank's `obj` as a list on rank 0 (None elsewhere); [obj] without a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
+
+
+def all_to_all_objects(obj):
+    """Every rank's `obj` as a list on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
+
+
+def finish():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def assign(n_items, rank, world):

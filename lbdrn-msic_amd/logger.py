@@ -6,6 +6,7 @@ Interface kept from the reference (ref logger.py:9-18): module attribute `log` w
 reference scrapes `MSE:`, `PSNR:`, `bpsp=`, `Total size: N bytes`, `Time elapsed:`, `nn: N bytes` and
 `MSB: N bytes` out of these files.
 """
+import contextlib
 import logging
 import pathlib
 import sys
@@ -40,6 +41,44 @@ def create_logger(exp_folder, file_name, log_file_only=False):
         path.parent.mkdir(parents=True, exist_ok=True)
         targets.append(logging.FileHandler(path, mode="w"))
     log = _RunLog(targets)
+
+
+class _Collector(logging.Handler):
+    def __init__(self, sink):
+        super().__init__()
+        self.sink = sink
+        self.setFormatter(logging.Formatter(RECORD_LAYOUT))
+
+    def emit(self, record):
+        self.sink.append(self.format(record))
+
+
+@contextlib.contextmanager
+def capture(exclusive=True):
+    """Collect the formatted records written inside the block (a rank of a multi-GPU run keeps the records
+    of its tiles until rank 0 writes them out in tile order).  exclusive: the other handlers stay silent."""
+    lines = []
+    held = log.handlers[:] if exclusive else []
+    for h in held:
+        log.removeHandler(h)
+    collector = _Collector(lines)
+    log.addHandler(collector)
+    try:
+        yield lines
+    finally:
+        log.removeHandler(collector)
+        for h in held:
+            log.addHandler(h)
+
+
+def replay(lines):
+    """Write records captured elsewhere, already formatted, to this run's targets."""
+    for h in log.handlers:
+        stream = getattr(h, "stream", None)
+        if stream is not None:
+            for line in lines:
+                stream.write(line + "\n")
+            h.flush()
 
 
 def destroy_logger():

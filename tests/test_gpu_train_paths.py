@@ -189,6 +189,47 @@ def test_cli_split_ratio_tiles(dev, tmp_path):
     assert rec.shape == img.shape and np.array_equal(rec >> 4, img >> 4)
 
 
+def test_tiles_sharded_over_two_ranks_equal_the_serial_run(dev, tmp_path):
+    """torchrun with two ranks (both on this box's one GPU; eight GPUs work the same way): the 3x3 tiles of
+    an image fitted round-robin by the ranks give byte for byte the .bin of the single-process run -- the RNG
+    replay of the tiles a rank skips included -- and the sharded decode reports the serial run's metrics.  Then
+    the sweep driver over two K values on two ranks, summarised into the CSV."""
+    import re
+    img = synthetic_tile(13, 4, 50, 62)
+    src = tmp_path / "scene.tif"
+    raster_io.write_raster(str(src), img)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    flags = ["-K", "4", "-D", "1", "-bs", "96", "-e", "3", "-sr", "3"]
+    pkg = os.path.join(ROOT, "lbdrn-msic_amd")
+    run2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+            "--master-addr", "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200)]
+    subprocess.run([sys.executable, os.path.join(pkg, "encode.py"), "-i", str(src), "-o", str(tmp_path / "one")] + flags,
+                   check=True, env=env, capture_output=True)
+    subprocess.run(run2 + [os.path.join(pkg, "encode.py"), "-i", str(src), "-o", str(tmp_path / "two")] + flags,
+                   check=True, env=env, capture_output=True, timeout=600)
+    sub = "scene_r3_K4_bc64_nl2_D1_prec16_lr0.001_bs96_e3"
+    a, b = (tmp_path / "one" / sub / "scene.bin").read_bytes(), (tmp_path / "two" / sub / "scene.bin").read_bytes()
+    assert a == b
+    subprocess.run([sys.executable, os.path.join(pkg, "decode.py"), "-i", str(tmp_path / "one" / sub / "scene.bin"),
+                    "-org", str(src)], check=True, env=env, capture_output=True)
+    subprocess.run(run2 + [os.path.join(pkg, "decode.py"), "-i", str(tmp_path / "two" / sub / "scene.bin"), "-org", str(src)],
+                   check=True, env=env, capture_output=True, timeout=600)
+    pick = lambda d: re.findall(r"(MSE: \S+|PSNR: \S+|Total size: .*)", (tmp_path / d / sub / "decode.txt").read_text())
+    assert pick("one") == pick("two") and len(pick("one")) == 3
+    # sweep: (image, K) points dealt over the two ranks, CSV written by rank 0
+    out = subprocess.run(run2 + [os.path.join(pkg, "sweep.py"), "--images", str(src), "--k", "3", "4", "-o",
+                                 str(tmp_path / "sw"), "-D", "1", "-bs", "96", "-e", "2", "--summary"],
+                         check=True, env=env, capture_output=True, text=True, timeout=600).stdout
+    assert "All files processed." in out and out.count(": ok in") == 2
+    import csv
+    rows = list(csv.reader(open(tmp_path / "sw" / "results_r1_bc64_nl2_D1_prec16_lr0.001_bs96_e2.csv")))
+    assert rows[0] == ["K", "scene_MSE", "scene_PSNR", "scene_bpsp", "scene_bits"]
+    assert [r[0] for r in rows[1:]] == ["K3", "K4"] and all(float(x) > 0 for r in rows[1:] for x in r[1:])
+    assert float(rows[1][1]) < float(rows[2][1])        # more bits kept exactly (smaller K) -> smaller error
+
+
 def test_full_size_properties(dev):
     """BASELINE.json configs[1] size: the two independent HIP implementations (generic tiled FMA
     kernels, fused MFMA kernel) agree bit for bit on the 33.5 M decoded sub-pixels, high bits are
