@@ -146,6 +146,23 @@ size_t lbdrn_randperm_workspace(int64_t n, int32_t count);
 int lbdrn_randperm(const uint64_t *seeds, int32_t count, int64_t n, int64_t *perm, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* MSB-plane payload "LBB2" -- stands where the reference calls an external lossless codec for the MSB raster
+ * (gdal_translate -of JP2OpenJPEG QUALITY=100 REVERSIBLE=YES, encode.py:137; read back at decode.py:69-73).
+ * The byte format is this library's own (oracle/plane_codec.c states it in full): lossless by construction,
+ * not JPEG 2000.  planes: [C][H][W] uint16 in HBM.  body: counts[C*ceil(W/64)] uint32 then the 32-bit words.
+ *   lbdrn_plane_bound      worst-case body size in bytes (size the output buffer with it)
+ *   lbdrn_plane_workspace  scratch bytes for either direction
+ *   lbdrn_plane_encode     writes the body and its length in bytes (*body_bytes, device memory)
+ *   lbdrn_plane_decode     rebuilds the planes; *status (device int32) is 0 for a well-formed body, non-zero
+ *                          when the stream was inconsistent (the planes are then unspecified, never out of
+ *                          bounds).  LBDRN_E_ARG when body_bytes cannot belong to this geometry. */
+size_t lbdrn_plane_bound(int32_t C, int32_t H, int32_t W);
+size_t lbdrn_plane_workspace(int32_t C, int32_t H, int32_t W);
+int lbdrn_plane_encode(const uint16_t *planes, int32_t C, int32_t H, int32_t W, void *body, size_t body_capacity,
+                       uint64_t *body_bytes, void *workspace, size_t workspace_bytes, void *stream);
+int lbdrn_plane_decode(const void *body, size_t body_bytes, int32_t C, int32_t H, int32_t W, uint16_t *planes,
+                       int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
 /* a7/a8 building block exposed for teacher-forced parity tests: one update on an explicit
  * minibatch x[B][F], t[B][C]; grads (optional) receives d(loss)/d(params). */
 int lbdrn_train_step(const lbdrn_net *net, const float *x, const float *t, int32_t B,

@@ -16,6 +16,12 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
                      size_t ws_bytes, hipStream_t s);
 int train_profile_mode(int mode);
 size_t randperm_workspace(int64_t n, int count);
+size_t plane_bound(int C, int H, int W);
+size_t plane_workspace(int C, int H, int W);
+int plane_encode(const uint16_t* planes, int C, int H, int W, void* body, size_t body_cap, uint64_t* body_bytes,
+                 void* ws, size_t ws_bytes, hipStream_t s);
+int plane_decode(const void* body, size_t body_bytes, int C, int H, int W, uint16_t* planes, int* status, void* ws,
+                 size_t ws_bytes, hipStream_t s);
 int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, void* ws, size_t ws_bytes,
                    hipStream_t s);
 }  // namespace lbdrn
@@ -246,6 +252,26 @@ int lbdrn_randperm(const uint64_t* seeds, int32_t count, int64_t n, int64_t* per
     LBDRN_REQUIRE(n >= 0 && (perm || n == 0), "bad n or null output");
     NEED_DEVICE();
     return randperm_batch(seeds, count, n, perm, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t lbdrn_plane_bound(int32_t C, int32_t H, int32_t W) { return plane_bound(C, H, W); }
+size_t lbdrn_plane_workspace(int32_t C, int32_t H, int32_t W) { return plane_workspace(C, H, W); }
+
+int lbdrn_plane_encode(const uint16_t* planes, int32_t C, int32_t H, int32_t W, void* body, size_t body_capacity,
+                       uint64_t* body_bytes, void* workspace, size_t workspace_bytes, void* stream)
+{
+    LBDRN_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad raster geometry");
+    NEED_DEVICE();
+    return plane_encode(planes, C, H, W, body, body_capacity, body_bytes, workspace, workspace_bytes,
+                        (hipStream_t)stream);
+}
+
+int lbdrn_plane_decode(const void* body, size_t body_bytes, int32_t C, int32_t H, int32_t W, uint16_t* planes,
+                       int32_t* status, void* workspace, size_t workspace_bytes, void* stream)
+{
+    LBDRN_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad raster geometry");
+    NEED_DEVICE();
+    return plane_decode(body, body_bytes, C, H, W, planes, status, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int lbdrn_train_step(const lbdrn_net* net, const float* x, const float* t, int32_t B, float* params,

@@ -32,7 +32,7 @@ def test(bitstream, dirname, filename, nn_bytes, base_bytes, write=True):
     (ref decode.py:56-141)."""
     nn_payload, bitstream = bitstream[:nn_bytes], bitstream[nn_bytes:]
     base_payload, bitstream = bitstream[:base_bytes], bitstream[base_bytes:]
-    base = container.decode_base(base_payload)
+    base = container.decode_base(base_payload, device=DEVICE, keep_on_device=True)   # ref decode.py:69-73
     params = container.decode_weights(nn_payload)
     image = codec.apply_image(base, params, K, D, bc, nl, cfg=FeatCfg.from_constants(), device=DEVICE)
     recon_path = f"{dirname}/{filename}_recon.tif"

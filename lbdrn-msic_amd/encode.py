@@ -24,6 +24,7 @@ from lbdrn_hip.features import FeatCfg
 from LBDRNdataset import tile_windows
 
 DEVICE = "cuda:0"
+BASE_CODEC = os.environ.get("LBDRN_BASE_CODEC", "LBB2")   # "LBB1": the portable host payload of older files
 
 
 def write_image_header(header_path, split_ratio, width, height, K, bc, nl, D, nn_bytes_list,
@@ -44,7 +45,7 @@ def train(args, img=None):
     filename = os.path.splitext(os.path.basename(args.path))[0]
     res = codec.fit_image(img, args.K, args.D, args.base_channel, args.num_layers, args.lr,
                           args.batch_size, args.epochs, args.val_duration,
-                          cfg=FeatCfg.from_constants(), device=DEVICE)
+                          cfg=FeatCfg.from_constants(), device=DEVICE, host_msb=False)
     logger.log.info("total_params: {}".format(res.params.size))
     for epoch, mse, improved in res.epoch_mse:
         if improved:
@@ -54,10 +55,21 @@ def train(args, img=None):
     logger.log.info("best epoch: {}".format(res.best_epoch))
     nn_payload = container.encode_weights(res.params, args.precision)      # ref encode.py:129
     logger.log.info(f"nn: {len(nn_payload)} bytes, bpsp={len(nn_payload) * 8 / res.n_subpixels}")
-    base_payload = container.encode_base(res.msb)                           # ref encode.py:137
+    # ref encode.py:137 (gdal_translate to JP2): here the plane is coded where the fit left it, in HBM;
+    # uint8 when it fits, like the reference's MSB raster (LBDRNdataset.py:100)
+    if BASE_CODEC == "LBB2":
+        base_payload = container.encode_base(res.msb_device, device=DEVICE, as_uint8=res.msb_max <= 255)
+    else:
+        base_payload = container.encode_base(_host_msb(res), codec=BASE_CODEC)
     logger.log.info(f"MSB: {len(base_payload)} bytes: bpsp={len(base_payload) * 8 / res.n_subpixels}")
     logger.log.info(f"{filename}: fit {res.seconds['fit']:.3f}s on {DEVICE}")
     return nn_payload, base_payload
+
+
+def _host_msb(res):
+    from lbdrn_hip import ops
+    msb = ops.from_device_u16(res.msb_device)
+    return msb.astype(np.uint8) if res.msb_max <= 255 else msb
 
 
 def build_parser():

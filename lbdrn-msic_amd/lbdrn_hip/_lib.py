@@ -53,6 +53,10 @@ SIGNATURES = {
     "lbdrn_train_profile_mode": (ctypes.c_int, [_i32]),
     "lbdrn_randperm_workspace": (_sz, [_i64, _i32]),
     "lbdrn_randperm": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), _i32, _i64, _vp, _vp, _sz, _vp]),
+    "lbdrn_plane_bound": (_sz, [_i32, _i32, _i32]),
+    "lbdrn_plane_workspace": (_sz, [_i32, _i32, _i32]),
+    "lbdrn_plane_encode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _sz, _vp]),
+    "lbdrn_plane_decode": (ctypes.c_int, [_vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "lbdrn_train_step": (ctypes.c_int, [_NP, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _dbl, _i32, _vp,
                                         _vp, _vp, _sz, _vp]),
 }

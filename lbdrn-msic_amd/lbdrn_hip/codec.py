@@ -46,7 +46,8 @@ class FitResult:
         self.best_mse = None
         self.epoch_mse = []         # (epoch, mse, improved)
         self.losses = None          # per-step minibatch losses [epochs][steps] (device tensor)
-        self.msb = None             # MSB plane, numpy uint8/uint16 [C,H,W]
+        self.msb = None             # MSB plane, numpy uint8/uint16 [C,H,W] (None with host_msb=False)
+        self.msb_device = None      # the same plane in HBM (uint16 bits in int16 storage)
         self.msb_max = None
         self.n_feature = None
         self.channels = None
@@ -141,8 +142,9 @@ def apply_device(geom, net, msb_d, params_d, path=ops.PATH_AUTO, ws=None, want_y
 
 
 def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, perm_workers=4):
-    """Host-array front end of fit_device(): img numpy uint16 [C,H,W] or [H,W] -> FitResult."""
+              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, host_msb=True):
+    """Host-array front end of fit_device(): img numpy uint16 [C,H,W] or [H,W] -> FitResult.
+    host_msb=False leaves the MSB plane in HBM only (the encoder codes it there)."""
     res = FitResult()
     t0 = time.time()
     img = np.ascontiguousarray(img, dtype=np.uint16)
@@ -163,8 +165,10 @@ def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_d
         if mse_host[e - 1, 1] > 0:
             res.best_epoch, res.best_mse = e, float(mse_host[e - 1, 0])
     res.params = fit.best_params.cpu().numpy()
-    msb = ops.from_device_u16(fit.msb)
-    res.msb = msb.astype(np.uint16) if fit.msb_max > 255 else msb.astype(np.uint8)   # LBDRNdataset.py:100
+    res.msb_device = fit.msb
+    if host_msb:
+        msb = ops.from_device_u16(fit.msb)
+        res.msb = msb.astype(np.uint16) if fit.msb_max > 255 else msb.astype(np.uint8)   # LBDRNdataset.py:100
     res.msb_max = fit.msb_max
     res.n_feature, res.channels, res.n_subpixels = fit.geom.F, C, H * W * C
     res.losses = fit.losses
@@ -174,15 +178,22 @@ def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_d
 def apply_image(base, params, K, D, base_channel, num_layers, cfg=None, device="cuda:0",
                 path=ops.PATH_AUTO, want_y=False):
     """Reconstruct one image (or tile) from its MSB plane and fitted weights (ref decode.py:73-134).
-    base: numpy [C,H,W] (uint8 or uint16); params: float32 vector in state_dict order."""
+    base: numpy [C,H,W] (uint8 or uint16), or the plane already in HBM (int16-storage tensor);
+    params: float32 vector in state_dict order."""
     cfg = cfg or FeatCfg.from_constants()
-    base = np.ascontiguousarray(base).astype(np.uint16)                   # decode.py:74
-    if base.ndim == 2:
-        base = base[None]
-    C, H, W = base.shape
     dev = torch.device(device)
-    msb_d = ops.to_device_u16(base, dev)
-    geom = ops.FeatureGeometry(C, H, W, K, D, int(base.max()), cfg, dev)  # divisor base.max(): decode.py:93
+    if isinstance(base, torch.Tensor):
+        msb_d = base if base.dim() == 3 else base[None]
+        # uint16 bits in int16 storage: the maximum as unsigned
+        msb_max = int((msb_d.to(torch.int32) & 0xFFFF).max().item())
+    else:
+        base = np.ascontiguousarray(base).astype(np.uint16)               # decode.py:74
+        if base.ndim == 2:
+            base = base[None]
+        msb_d = ops.to_device_u16(base, dev)
+        msb_max = int(base.max())
+    C, H, W = msb_d.shape
+    geom = ops.FeatureGeometry(C, H, W, K, D, msb_max, cfg, dev)         # divisor base.max(): decode.py:93
     net = ops.make_net(geom.F, base_channel, C, num_layers)
     p = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float32)).to(dev)
     if p.numel() != ops.param_count(net):

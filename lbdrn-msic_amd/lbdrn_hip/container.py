@@ -18,6 +18,7 @@ import numpy as np
 
 NN_PRIVATE_MAGIC = b"LBW1"
 BASE_PRIVATE_MAGIC = b"LBB1"
+BASE_LBB2_MAGIC = b"LBB2"
 
 
 # ---------------------------------------------------------------- header
@@ -130,11 +131,25 @@ def _have_gdal_jp2():
         return False
 
 
-def encode_base(msb):
-    """Lossless MSB plane [C,H,W] (uint8 when max <= 255 else uint16, ref LBDRNdataset.py:100).
+def encode_base(msb, codec="LBB2", device="cuda:0", as_uint8=None):
+    """Lossless MSB plane [C,H,W] (uint8 when max <= 255 else uint16, ref LBDRNdataset.py:100); stands where
+    the reference runs gdal_translate to JPEG 2000 (ref encode.py:137).
 
-    Private payload: the plane predictor x[i,j] - x[i-1,j] - x[i,j-1] + x[i-1,j-1] (mod 2^16),
-    zig-zag folded, high and low bytes split, LZMA."""
+    LBB2 (default): coded on the GPU by lbdrn_plane_encode (csrc/plane_codec.hip) -- msb may be a numpy array
+    or the device tensor the fit left in HBM (then as_uint8 says which dtype the decoder hands back).  LBB1: the portable host codec of earlier bitstreams (plane
+    predictor + LZMA; a minute per 8 x 2048^2 tile), kept so that those files still decode and for hosts
+    that only need to write small rasters."""
+    if codec == "LBB2":
+        from . import ops
+        if isinstance(msb, np.ndarray):
+            code = 1 if msb.dtype == np.uint8 else 2
+            planes = ops.to_device_u16(np.ascontiguousarray(msb).astype(np.uint16), device)
+        else:
+            planes, code = msb, (1 if as_uint8 else 2)
+        C, H, W = planes.shape
+        return BASE_LBB2_MAGIC + struct.pack(">BHII", code, C, H, W) + ops.plane_encode(planes)
+    if codec != "LBB1":
+        raise ValueError(f"unknown MSB payload codec {codec!r}")
     msb = np.ascontiguousarray(msb)
     C, H, W = msb.shape
     code = 1 if msb.dtype == np.uint8 else 2
@@ -150,7 +165,18 @@ def encode_base(msb):
     return BASE_PRIVATE_MAGIC + struct.pack(">BHII", code, C, H, W) + body
 
 
-def decode_base(buf):
+def decode_base(buf, device="cuda:0", keep_on_device=False):
+    """MSB payload -> [C,H,W] numpy (uint8 / uint16 as encoded).  keep_on_device: an LBB2 payload is returned
+    as the device tensor it was decoded into (uint16 bits, int16 storage) -- decode.py feeds it straight to
+    the apply kernel."""
+    if buf[:4] == BASE_LBB2_MAGIC:
+        from . import ops
+        code, C, H, W = struct.unpack_from(">BHII", buf, 4)
+        planes = ops.plane_decode(bytes(buf[15:]), C, H, W, device)
+        if keep_on_device:
+            return planes
+        x = ops.from_device_u16(planes)
+        return x.astype(np.uint8) if code == 1 else x
     if buf[:4] != BASE_PRIVATE_MAGIC:
         raise ValueError("MSB payload is not this package's private format (a JPEG 2000 stream "
                          "written by the reference needs GDAL/OpenJPEG, which is not installed)")

@@ -220,6 +220,34 @@ def randperm(seeds, n, device):
     return out[0] if scalar else out
 
 
+def plane_encode(planes):
+    """[C,H,W] uint16 planes in HBM -> LBB2 body as host bytes (counts + words; container.py adds the tag).
+    One host sync: the body's length decides how much is copied back."""
+    _need_cuda(planes)
+    planes = _u16(planes.contiguous())
+    C, H, W = planes.shape
+    dev = planes.device
+    body = torch.empty(lib().lbdrn_plane_bound(C, H, W), dtype=torch.uint8, device=dev)
+    nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(lib().lbdrn_plane_workspace(C, H, W), 1), dtype=torch.uint8, device=dev)
+    check(lib().lbdrn_plane_encode(_ptr(planes), C, H, W, _ptr(body), body.numel(), _ptr(nbytes), _ptr(ws),
+                                   ws.numel(), _stream()))
+    return body[:int(nbytes.item())].cpu().numpy().tobytes()
+
+
+def plane_decode(body, C, H, W, device):
+    """LBB2 body (bytes) -> [C,H,W] uint16 planes in HBM (int16 storage).  Raises on a malformed stream."""
+    raw = torch.frombuffer(bytearray(body), dtype=torch.uint8).to(device)
+    planes = torch.empty((C, H, W), dtype=torch.int16, device=device)
+    status = torch.zeros(1, dtype=torch.int32, device=device)
+    ws = torch.empty(max(lib().lbdrn_plane_workspace(C, H, W), 1), dtype=torch.uint8, device=device)
+    check(lib().lbdrn_plane_decode(_ptr(raw), raw.numel(), C, H, W, _ptr(planes), _ptr(status), _ptr(ws),
+                                   ws.numel(), _stream()))
+    if int(status.item()):
+        raise _lib.LbdrnError("LBB2 payload is inconsistent with its geometry (corrupt or truncated stream)")
+    return planes
+
+
 def to_device_u16(arr, device):
     """numpy uint16 array -> device tensor (int16 storage, same bits)."""
     a = np.ascontiguousarray(arr, dtype=np.uint16)

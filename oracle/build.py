@@ -1,4 +1,4 @@
-"""Compile oracle/lbdrn_oracle.c into oracle/_build/liblbdrn_oracle.so.
+"""Compile oracle/lbdrn_oracle.c and oracle/plane_codec.c into oracle/_build/liblbdrn_oracle.so.
 
 TEST INFRASTRUCTURE.  Called from __graft_entry__.build() and lazily from
 oracle/oracle.py.  -ffp-contract=off keeps gcc from fusing the explicit
@@ -11,17 +11,17 @@ import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "lbdrn_oracle.c")
+SRCS = [os.path.join(HERE, "lbdrn_oracle.c"), os.path.join(HERE, "plane_codec.c")]
 OUT_DIR = os.path.join(HERE, "_build")
 OUT = os.path.join(OUT_DIR, "liblbdrn_oracle.so")
 
 
 def build(force=False):
     os.makedirs(OUT_DIR, exist_ok=True)
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= os.path.getmtime(SRC):
+    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(map(os.path.getmtime, SRCS)):
         return OUT
     cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-ffp-contract=off", "-fno-fast-math",
-           "-Wall", "-o", OUT, SRC, "-lm"]
+           "-Wall", "-o", OUT] + SRCS + ["-lm"]
     subprocess.check_call(cmd)
     return OUT
 

@@ -288,3 +288,29 @@ def synthetic_tile(i, C=8, H=2048, W=2048):
         acc += rng.normal(0.0, 40.0, (H, W))
         img[c] = np.clip(np.rint(acc), 0, 10000).astype(np.uint16)
     return img
+
+
+# ---------------------------------------------------------------- LBB2 MSB-plane payload (oracle/plane_codec.c)
+
+def plane_encode(planes):
+    """[C,H,W] uint16 -> (counts uint32[nstrips], words uint32[nw]) of the LBB2 body."""
+    x = _c(planes, np.uint16)
+    C, H, W = x.shape
+    L = lib()
+    L.orc_plane_nstrips.restype = ctypes.c_int64
+    L.orc_plane_encode.restype = ctypes.c_int64
+    ns = int(L.orc_plane_nstrips(C, H, W))
+    counts = np.zeros(ns, np.uint32)
+    cap = ns * (2 + (H + 63) // 64 * (1 + 64 * 64) + 64)
+    words = np.zeros(cap, np.uint32)
+    nw = int(L.orc_plane_encode(_p(x), C, H, W, _p(counts), _p(words), ctypes.c_int64(cap)))
+    assert nw >= 0
+    return counts, words[:nw].copy()
+
+
+def plane_decode(counts, words, C, H, W):
+    out = np.zeros((C, H, W), np.uint16)
+    rc = lib().orc_plane_decode(_p(_c(counts, np.uint32)), _p(_c(words, np.uint32)), C, H, W, _p(out))
+    if rc:
+        raise ValueError(f"LBB2 stream rejected by the oracle decoder ({rc})")
+    return out
