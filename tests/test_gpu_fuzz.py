@@ -214,3 +214,60 @@ def test_activation_special_values_equal_oracle(dev):
         y = ops.forward(net, torch.from_numpy(p2).to(dev), torch.zeros(3, 1, device=dev)).cpu().numpy()
         yo = O.forward(p2, F, bc, C, nl, np.zeros((3, 1), np.float32))
         assert np.array_equal(y.view(np.int32), yo.view(np.int32)), b1
+
+
+def test_cli_fuzz_encode_decode_in_process(dev, tmp_path, monkeypatch):
+    """encode.main -> .bin -> decode.main over random small rasters and flag combinations (bands, odd sizes,
+    K that make the MSB plane uint8 or uint16, D = 0, tiles): the written raster keeps the high bits, equals
+    the oracle's decode of the payloads in the file, and the logged MSE is the raster's."""
+    import re
+    import decode
+    import encode
+    from lbdrn_hip import container, raster_io
+    from LBDRNdataset import tile_windows
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    rng = np.random.default_rng(99)
+    for it in range(6 * SOAK):
+        C = int(rng.integers(1, 7))
+        H, W = int(rng.integers(9, 80)), int(rng.integers(9, 90))
+        K = int(rng.choice([1, 3, 5, 8, 11]))
+        D = int(rng.integers(0, 3))
+        sr = int(rng.choice([1, 1, 2, 3]))
+        if min(H, W) // sr <= D + 1:
+            sr = 1
+        hi = int(rng.choice([1023, 10000, 65535]))
+        img = rng.integers(0, hi + 1, (C, H, W)).astype(np.uint16)
+        src = str(tmp_path / f"img{it}.npy")
+        np.save(src, img)
+        out = str(tmp_path / f"o{it}")
+        flags = ["-K", str(K), "-D", str(D), "-bs", "128", "-e", "2", "-sr", str(sr), "-nl", str(int(rng.integers(1, 4)))]
+        tag = (it, C, H, W, flags)
+        assert encode.main(["-i", src, "-o", out] + flags) == 0, tag
+        sub = [d for d in os.listdir(out)][0]
+        binp = os.path.join(out, sub, f"img{it}.bin")
+        raw = open(binp, "rb").read()
+        n, sr_, w_, h_, K_, bc_, nl_, D_, nn, base = container.unpack_header(raw)
+        assert (sr_, w_, h_, K_, D_) == (sr, W, H, K, D), tag
+        assert decode.main(["-i", binp]) == 0, tag
+        rec = raster_io.read_raster(os.path.join(out, sub, f"img{it}_recon.tif")).reshape(C, H, W)
+        assert np.array_equal(rec >> K, img >> K), tag
+        # the oracle decodes every tile's payloads to the same pixels
+        ocfg = O.FeatCfg()
+        off = n
+        wins = list(tile_windows(W, H, sr)) if sr > 1 else [(0, 0, 0, 0, W, H)]
+        for t, (_, _, x0, y0, w, h) in enumerate(wins):
+            params = container.decode_weights(raw[off:off + nn[t]])
+            msb = container.decode_base(raw[off + nn[t]:off + nn[t] + base[t]])
+            off += nn[t] + base[t]
+            assert np.array_equal(msb, img[:, y0:y0 + h, x0:x0 + w] >> K), tag
+            assert msb.dtype == (np.uint8 if int(msb.max()) <= 255 else np.uint16), tag
+            if int(msb.max()) > 0:
+                ro = O.decode(msb.astype(np.uint16), K, D, ocfg, params, bc_, nl_)
+                assert np.array_equal(rec[:, y0:y0 + h, x0:x0 + w], ro), tag
+        assert off == len(raw), tag
+        assert decode.main(["-i", binp, "-org", src]) == 0    # decode.txt has no bpsp yet: runs again with metrics
+        log = open(os.path.join(out, sub, "decode.txt")).read()
+        mse = float(re.search(r"MSE: (\S+)", log).group(1))
+        true = float(np.mean((img.astype(np.float32) - rec.astype(np.float32)) ** 2))
+        assert abs(mse - true) <= 1e-4 * max(true, 1e-9), tag
