@@ -5,7 +5,6 @@ __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
 Citations are relative to /root/reference.
 """
 import ctypes
-import math
 import os
 import sys
 
@@ -267,27 +266,6 @@ def sin_ref(x):
 def sigmoid_ref(x):
     return np.array([lib().orc_sigmoid(float(v)) for v in np.asarray(x, np.float32).ravel()],
                     np.float32).reshape(np.shape(x))
-
-
-def synthetic_tile(i, C=8, H=2048, W=2048):
-    """SURVEY.md 8(d) synthetic tile i: per band six low-frequency 2-D sinusoids scaled to
-    [500,9500] plus N(0,40^2) noise, rounded and clipped to [0,10000]; default_rng(1000+i)."""
-    rng = np.random.default_rng(1000 + i)
-    yy = np.arange(H, dtype=np.float64)[:, None] / max(H, 1)
-    xx = np.arange(W, dtype=np.float64)[None, :] / max(W, 1)
-    img = np.empty((C, H, W), np.uint16)
-    for c in range(C):
-        acc = np.zeros((H, W))
-        for _ in range(6):
-            fy, fx = rng.uniform(0.5, 6.0, 2)
-            ph = rng.uniform(0, 2 * math.pi)
-            amp = rng.uniform(0.3, 1.0)
-            acc += amp * np.sin(2 * math.pi * (fy * yy + fx * xx) + ph)
-        lo, hi = acc.min(), acc.max()
-        acc = 500.0 + (acc - lo) / max(hi - lo, 1e-12) * 9000.0
-        acc += rng.normal(0.0, 40.0, (H, W))
-        img[c] = np.clip(np.rint(acc), 0, 10000).astype(np.uint16)
-    return img
 
 
 # ---------------------------------------------------------------- LBB2 MSB-plane payload (oracle/plane_codec.c)
