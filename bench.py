@@ -6,7 +6,9 @@
 
 A "step" is one pass of the hot path over one synthetic tile: the fused fit (bit split, 10 epochs of
 minibatch Adam with a whole-image evaluation after each, best-epoch selection), the 16-bit weight
-truncation the bitstream applies, and the fused apply (reconstruction).  Each rank owns its own
+truncation the bitstream applies, and the fused apply (reconstruction).  The K tiles of the timed region are
+independent fits; --in-flight of them (default 2) progress at a time on each GPU, on their own streams,
+which fills the idle gaps of one fit's chain of short dependent kernels.  Each rank owns its own
 tiles (images are independent fits): weak scaling, no data-path collective; RCCL
 carries only the max-over-ranks time and the per-image metric records.  Inputs are resident in HBM
 when the timed region starts; host work that belongs to the path (the permutations of
@@ -46,6 +48,8 @@ def parse():
     p.add_argument("--path", choices=["auto", "generic", "mfma"], default="auto")
     p.add_argument("--coords-embedding", action="store_true",
                    help="BASELINE.json configs[4]: USE_COORDINATES=True + EMBEDDING=True (F = 250)")
+    p.add_argument("--in-flight", type=int, default=2,
+                   help="tiles progressing at a time on each GPU (independent fits on their own streams)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=192, help="side of the CPU-baseline crop")
     return p.parse_args()
@@ -56,13 +60,14 @@ def feat_cfg(a):
     return FeatCfg(use_coordinates=a.coords_embedding, embedding=a.coords_embedding)
 
 
-def one_image(codec, ops, img_d, a, path):
-    """encode (fit) + weight truncation + decode (apply) for one HBM-resident tile."""
-    torch.manual_seed(SEED)  # every encode.py invocation seeds itself (ref encode.py:200-205)
-    fit = codec.fit_device(img_d, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=feat_cfg(a), path=path)
-    params = codec.truncate_device(fit.best_params, 16)
-    rec = codec.apply_device(fit.geom, fit.net, fit.msb, params, path=path)
-    return fit, rec
+def run_images(codec, ops, tiles, a, path):
+    """encode (fit) + weight truncation + decode (apply) for each HBM-resident tile; a.in_flight tiles progress
+    at a time.  Every fit seeds itself like an encode.py invocation does (ref encode.py:200-205)."""
+    def finish(fit):
+        params = codec.truncate_device(fit.best_params, 16)
+        return fit, codec.apply_device(fit.geom, fit.net, fit.msb, params, path=path)
+    return codec.fit_many(tiles, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=feat_cfg(a), path=path,
+                          seed=SEED, in_flight=a.in_flight, then=finish)
 
 
 def flops_per_pixel(F, bc, C, nl):
@@ -178,10 +183,18 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (liblbdrn_hip has no CPU path)", file=sys.stderr)
         return 2
+    # one process per GPU.  LBDRN_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
+    # (ranks then share devices round-robin and the three scalars per rank travel over gloo instead of RCCL)
+    backend = os.environ.get("LBDRN_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    xdev = dev if backend == "nccl" else None   # where the exchanged scalars live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from lbdrn_hip import codec, ops, shard
     from lbdrn_hip.synth import synthetic_tile
     path = {"auto": ops._lib.PATH_AUTO, "generic": ops._lib.PATH_GENERIC, "mfma": ops._lib.PATH_MFMA}[a.path]
@@ -198,24 +211,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        one_image(codec, ops, tiles[i], a, path)
+    run_images(codec, ops, tiles[:a.warmup], a, path)
     barrier()
     t0 = time.perf_counter()
-    last = None
-    records = []
-    for i in range(a.warmup, total):
-        fit, rec = one_image(codec, ops, tiles[i], a, path)
-        last = (fit, rec, tiles[i])
+    done = run_images(codec, ops, tiles[a.warmup:], a, path)
     barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
+    last = done[-1] + (tiles[-1],)
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, xdev)
 
     # per-image metric record of the last tile (after the clock): MSE / PSNR of the reconstruction
     fit, rec, img_d = last
     diff = (img_d.view(torch.int16).to(torch.int32) & 0xFFFF).float() - (rec.to(torch.int32) & 0xFFFF).float()
     mse = float((diff * diff).mean().item())
     # [image index, reconstruction MSE, best evaluation MSE]: the only data the ranks exchange
-    records = shard.gather_records([[float(mine[-1]), mse, float(fit.mse_log[:, 0].min().item())]], 3, dev)
+    records = shard.gather_records([[float(mine[-1]), mse, float(fit.mse_log[:, 0].min().item())]], 3, xdev)
 
     if rank == 0:
         px = a.height * a.width
@@ -230,7 +239,8 @@ def main():
                                    f"K={a.K} D={a.D} bc={a.bc} nl={a.nl} bs={a.bs} e={a.epochs}"
                                    f"{' USE_COORDINATES+EMBEDDING' if a.coords_embedding else ''} "
                                    f"(BASELINE.json configs[1] by default); encode fit + 16-bit weight truncation + decode",
-                       "tiles_per_gpu": a.steps, "parallelism": f"image-sharded x{world}", "path": a.path},
+                       "tiles_per_gpu": a.steps, "tiles_in_flight_per_gpu": min(a.in_flight, a.steps),
+                       "parallelism": f"image-sharded x{world}", "path": a.path},
             "recon_mse_last_tile": round(mse, 4),
             "recon_psnr_last_tile": round(10 * np.log10(10000 ** 2 / max(mse, 1e-12)), 3),
             "records": records,

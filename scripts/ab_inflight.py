@@ -1,0 +1,19 @@
+"""A/B aid: wall time per tile of codec.fit_many over 6 tiles with 1 and 2 fits in flight, for the train
+kernel named by LBDRN_TRAIN_KERNEL (unset = k_train_mfma, 'lean' = k_train_lean)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "lbdrn-msic_amd"))
+import torch
+from lbdrn_hip import codec, ops
+from lbdrn_hip.synth import synthetic_tile
+dev = torch.device("cuda:0")
+tiles = [ops.to_device_u16(synthetic_tile(i, 8, 2048, 2048), dev) for i in range(3)] * 2
+args = (5, 2, 64, 2, 1e-3, 8192, 10)
+out = []
+for infl in (1, 2):
+    codec.fit_many(tiles[:2], *args, seed=19920517, in_flight=infl)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    fits = codec.fit_many(tiles, *args, seed=19920517, in_flight=infl)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / len(tiles)
+    out.append(f"in_flight={infl}: {dt*1e3:.2f} ms/tile")
+print(os.environ.get("LBDRN_TRAIN_KERNEL", "mfma"), " | ".join(out), "mse", [round(float(f.mse_log[:, 0].min()), 6) for f in fits[:3]])

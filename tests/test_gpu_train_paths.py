@@ -320,3 +320,32 @@ def test_large_tile_64bit_indexing(dev):
     assert torch.equal(a, b)
     rec = ops.from_device_u16(a[:, -64:, :])
     assert np.array_equal(rec >> K, img[:, -64:, :] >> K)
+
+
+def test_fits_in_flight_together_equal_fits_one_by_one(dev):
+    """codec.fit_many: several images progressing at once on their own streams and host threads give, bit for
+    bit, what fitting them one after another gives (each fit seeds the shared generator itself, inside one
+    critical section with all its draws)."""
+    shapes = [(4, 70, 90), (8, 64, 64), (3, 100, 41), (8, 96, 80), (4, 70, 90)]
+    imgs = [ops.to_device_u16(synthetic_tile(20 + i, *s), dev) for i, s in enumerate(shapes)]
+    args = (5, 2, 64, 2, 1e-3, 256, 4)
+    one_by_one = []
+    for img_d in imgs:
+        torch.manual_seed(19920517)
+        one_by_one.append(codec.fit_device(img_d, *args))
+    for in_flight in (2, 3):
+        together = codec.fit_many(imgs, *args, seed=19920517, in_flight=in_flight)
+        torch.cuda.synchronize()
+        for a, b in zip(one_by_one, together):
+            assert torch.equal(a.best_params.view(torch.int32), b.best_params.view(torch.int32))
+            assert torch.equal(a.mse_log, b.mse_log)
+    # `then` runs on the worker's stream; results come back in input order
+    recs = codec.fit_many(imgs, *args, seed=19920517, in_flight=2,
+                          then=lambda fit: codec.apply_device(fit.geom, fit.net, fit.msb,
+                                                              codec.truncate_device(fit.best_params, 16)))
+    torch.cuda.synchronize()
+    for img_d, rec in zip(imgs, recs):
+        assert rec.shape == img_d.shape
+        assert torch.equal((rec.to(torch.int32) & 0xFFFF) >> 5, (img_d.to(torch.int32) & 0xFFFF) >> 5)
+    with pytest.raises(ValueError):
+        codec.fit_many(imgs, *args, seed=None, in_flight=2)
