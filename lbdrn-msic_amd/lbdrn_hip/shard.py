@@ -26,8 +26,8 @@ def init_host_group():
 
 
 def device_for(local_rank):
-    """One process per GPU; ranks beyond the device count share devices round-robin (rehearsals on a
-    one-GPU box)."""
+    """One process per GPU; ranks beyond the device count share devices round-robin (two processes per GPU
+    is a useful setting for sweeps: the second fit fills the idle gaps of the first one's kernel chain)."""
     n = torch.cuda.device_count()
     return f"cuda:{local_rank % n}" if n else "cuda:0"
 
