@@ -33,7 +33,7 @@ SEED = 19920517  # ref encode.py:169
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=2)
+    p.add_argument("--steps", type=int, default=4)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--height", type=int, default=2048)
     p.add_argument("--width", type=int, default=2048)
@@ -122,8 +122,11 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
         out.update({"kernel": "k_train_mfma (gather+forward+loss+backward+dW slab, one 8192-row minibatch)",
                     "kernel_us": round(t_k * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
                     "flop_per_launch": step * B,
-                    "timing": "HIP events over one 512-step epoch, and over one with the reduce launch doubled; "
-                              "kernel_us = step - reduce, inside the real launch sequence"})
+                    "timing": "HIP events over one 512-step epoch of ONE fit on the launch stream, and over one with the "
+                              "reduce launch doubled; kernel_us = step - reduce, inside the real launch sequence. "
+                              "rocprofv3 agrees on the same one-fit sequence (profiles/r01_final_kernel_stats_one_in_flight.csv: "
+                              "19.5 us); with two fits in flight (the timed region) a trace's per-launch durations also "
+                              "contain the other fit's co-running reduce kernels (..._two_in_flight.csv: 24.2 us)"})
     else:  # shape without an MFMA train kernel: the generic step is many launches
         t_k = t_epoch / nsteps
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
