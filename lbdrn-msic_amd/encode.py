@@ -25,6 +25,7 @@ from LBDRNdataset import tile_windows
 
 DEVICE = "cuda:0"
 BASE_CODEC = os.environ.get("LBDRN_BASE_CODEC", "LBB2")   # "LBB1": the portable host payload of older files
+IN_FLIGHT = int(os.environ.get("LBDRN_IN_FLIGHT", "2"))    # tiles of one image progressing at a time on a GPU
 
 
 def write_image_header(header_path, split_ratio, width, height, K, bc, nl, D, nn_bytes_list,
@@ -42,10 +43,15 @@ def train(args, img=None):
     (ref encode.py:67-157)."""
     if img is None:
         img = raster_io.read_raster(args.path)
-    filename = os.path.splitext(os.path.basename(args.path))[0]
     res = codec.fit_image(img, args.K, args.D, args.base_channel, args.num_layers, args.lr,
                           args.batch_size, args.epochs, args.val_duration,
                           cfg=FeatCfg.from_constants(), device=DEVICE, host_msb=False)
+    return report_and_pack(args, res)
+
+
+def report_and_pack(args, res):
+    """The records train() logs for one finished fit, and its two payloads."""
+    filename = os.path.splitext(os.path.basename(args.path))[0]
     logger.log.info("total_params: {}".format(res.params.size))
     for epoch, mse, improved in res.epoch_mse:
         if improved:
@@ -64,6 +70,17 @@ def train(args, img=None):
     logger.log.info(f"MSB: {len(base_payload)} bytes: bpsp={len(base_payload) * 8 / res.n_subpixels}")
     logger.log.info(f"{filename}: fit {res.seconds['fit']:.3f}s on {DEVICE}")
     return nn_payload, base_payload
+
+
+def train_tiles(args, tiles, draws):
+    """Several tiles of one image: fitted with IN_FLIGHT of them progressing at a time (their random draws
+    were made beforehand, in tile order), then reported one after another like train() would.
+    tiles: [(path, array)]; returns [(nn_payload, base_payload, log records or None)]."""
+    results = codec.fit_images([arr for _, arr in tiles], args.K, args.D, args.base_channel, args.num_layers,
+                               args.lr, args.batch_size, args.epochs, args.val_duration,
+                               cfg=FeatCfg.from_constants(), device=DEVICE, host_msb=False, draws=draws,
+                               in_flight=IN_FLIGHT)
+    return results
 
 
 def _host_msb(res):
@@ -137,26 +154,31 @@ def main(argv=None, shard_tiles=None):
     height, width = img.shape[-2:]
     windows = list(tile_windows(width, height, args.split_ratio)) if args.split_ratio > 1 else [None]
     n_feature = FeatCfg.from_constants().feature_dim(img.shape[0], args.D)
-    fitted = []   # (tile index, nn payload, MSB payload, captured log records or None)
-    for t, win in enumerate(windows):
-        tile = img
-        if win is not None:
-            i, j, x0, y0, w, h = win
-            args.path = f"{args.output_dir}/tile_{i}_{j}.tif"
+    # every tile's random draws, in tile order, whoever fits it: the reference runs the tiles one after
+    # another on one generator (ref encode.py:231-262)
+    C = img.shape[0]
+    draws = [codec.draw_fit(n_feature, args.base_channel, C, args.num_layers, args.epochs, args.val_duration)
+             for _ in windows]
+    mine, jobs = [t for t in range(len(windows)) if t % world == rank], []
+    for t in mine:
+        path, tile = org_path, img
+        if windows[t] is not None:
+            i, j, x0, y0, w, h = windows[t]
+            path = f"{args.output_dir}/tile_{i}_{j}.tif"
             tile = np.ascontiguousarray(img[:, y0:y0 + h, x0:x0 + w])
-        if t % world != rank:
-            if not args.randomness:
-                codec.skip_fit_rng(n_feature, args.base_channel, img.shape[0], args.num_layers, args.epochs,
-                                   args.val_duration)
-            continue
+        jobs.append((path, tile))
+    results = train_tiles(args, jobs, [draws[t] for t in mine]) if jobs else []
+    fitted = []   # (tile index, nn payload, MSB payload, captured log records or None)
+    for t, (path, _), res in zip(mine, jobs, results):
+        args.path = path
         if world > 1:
             with logger.capture() as lines:
                 logger.log.info(args)
-                nn, base = train(args, tile)
+                nn, base = report_and_pack(args, res)
         else:
             lines = None
             logger.log.info(args)
-            nn, base = train(args, tile)
+            nn, base = report_and_pack(args, res)
         fitted.append((t, nn, base, lines))
     gathered = shard.gather_to_root(fitted) if world > 1 else [fitted]
     if rank == 0:

@@ -14,7 +14,7 @@ import torch
 from . import ops
 from .features import FeatCfg
 from .model import LBDRNModel
-from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, draw_iterator_seed, epoch_plan
+from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, draw_iterator_seed, draw_pass_seeds, epoch_plan
 
 
 def lr_schedule(lr, epochs):
@@ -36,9 +36,24 @@ def skip_fit_rng(n_feature, base_channel, channels, num_layers, epochs, val_dura
     so tile t's initial weights and minibatch orders depend on how much tiles 0..t-1 drew; a rank that
     fits only some of the tiles calls this for the ones it leaves to other ranks and so reproduces the
     serial run bit for bit."""
-    LBDRNModel(dim_in=n_feature, dim_hidden=base_channel, dim_out=channels, num_layers=num_layers)
-    for _ in epoch_plan(epochs, val_duration):
-        draw_iterator_seed()
+    draw_fit(n_feature, base_channel, channels, num_layers, epochs, val_duration)
+
+
+class FitDraws:
+    """Everything one fit takes from the global torch generator, drawn ahead of time: the initial parameters
+    (state_dict order) and the sampler seeds of its training passes."""
+
+    def __init__(self, params, train_seeds):
+        self.params, self.train_seeds = params, train_seeds
+
+
+def draw_fit(n_feature, base_channel, channels, num_layers, epochs, val_duration=1):
+    """Make the draws of one fit now, on the calling thread (same consumption as skip_fit_rng /
+    fit_device): the fits of the tiles of one image share ONE generator in the reference
+    (ref encode.py:231-262), so they can only progress together (fit_many) if each one's draws are taken
+    in tile order beforehand."""
+    model = LBDRNModel(dim_in=n_feature, dim_hidden=base_channel, dim_out=channels, num_layers=num_layers)
+    return FitDraws(model.flat_parameters(), draw_pass_seeds(epoch_plan(epochs, val_duration)))
 
 
 class FitResult:
@@ -76,7 +91,7 @@ _RNG_LOCK = threading.Lock()   # the global torch CPU generator is one per proce
 
 
 def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1,
-               cfg=None, path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, seed=None):
+               cfg=None, path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, seed=None, draws=None):
     """Fit one image that already sits in HBM (img_d: [C,H,W] uint16 bits in int16 storage), on the
     calling thread's current stream.
 
@@ -84,7 +99,8 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     exactly as the reference's train() consumes it: model construction, then one DataLoader
     iterator per train / eval pass (lbdrn_hip.sampler).  With `seed`, the fit seeds the generator
     itself and makes all its draws in one critical section, so that fits running on several
-    threads (fit_many) each see what a freshly seeded process would.  No host synchronisation
+    threads (fit_many) each see what a freshly seeded process would; with `draws` (draw_fit) the generator
+    is not touched at all.  No host synchronisation
     happens inside except the scalar read of MSB.max() that sizes the normalisation
     (ref LBDRNdataset.py:120)."""
     cfg = cfg or FeatCfg.from_constants()
@@ -98,14 +114,18 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
         raise ops._lib.LbdrnError(
             f"{N} pixels in one fit: torch.randperm switches algorithm at 2^32/20 elements and lbdrn_randperm "
             "implements the Fisher-Yates branch only; split the image (-sr) -- there is no host fallback")
-    with _RNG_LOCK:
-        if seed is not None:
-            torch.manual_seed(seed)
-        # model on the CPU first, like the reference (encode.py:71-77): consumes the global generator
-        model = LBDRNModel(dim_in=geom.F, dim_hidden=base_channel, dim_out=C, num_layers=num_layers)
-        stream = DevicePermutationStream(N, epochs, val_duration, dev)   # draws every pass's sampler seed
-    net = model.hip_net()
-    params = model.flat_parameters().to(dev).contiguous()
+    if draws is None:
+        with _RNG_LOCK:
+            if seed is not None:
+                torch.manual_seed(seed)
+            # model on the CPU first, like the reference (encode.py:71-77): consumes the global generator;
+            # then every pass's sampler seed
+            draws = draw_fit(geom.F, base_channel, C, num_layers, epochs, val_duration)
+    stream = DevicePermutationStream(N, epochs, val_duration, dev, train_seeds=draws.train_seeds)
+    net = ops.make_net(geom.F, base_channel, C, num_layers)
+    params = draws.params.to(dev).contiguous()
+    if params.numel() != ops.param_count(net):
+        raise ValueError("draws were made for another network shape")
     exp_avg = torch.zeros_like(params)
     exp_avg_sq = torch.zeros_like(params)
     lrs = lr_schedule(lr, epochs)
@@ -140,7 +160,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
 
 
 def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-             path=ops.PATH_AUTO, seed=19920517, in_flight=2, then=None):
+             path=ops.PATH_AUTO, seed=19920517, in_flight=2, then=None, draws=None):
     """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time, each on
     its own stream and host thread; returns [then(fit) or fit, ...] in input order.
 
@@ -150,34 +170,41 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     fits and every fit seeds the generator itself (`seed`, what each encode.py invocation does,
     ref encode.py:200-205), so results are bit-identical to fitting them one after another.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
-    coding, ...).  Returns after all streams have been joined to the caller's current stream."""
-    if seed is None and in_flight > 1 and len(images) > 1:
-        raise ValueError("fits in flight together must seed themselves (seed=...): they share one generator")
+    coding, ...).  `draws`: one FitDraws per image instead of `seed` (the tiles of one image, whose draws the
+    caller made in tile order).  Returns after all streams have been joined to the caller's current stream."""
+    if draws is not None:
+        seed = None
+        if len(draws) != len(images):
+            raise ValueError("one FitDraws per image expected")
+    elif seed is None and in_flight > 1 and len(images) > 1:
+        raise ValueError("fits in flight together must seed themselves (seed=...) or bring their draws: "
+                         "they share one generator")
     caller = torch.cuda.current_stream(images[0].device) if images else None
     local = threading.local()
 
-    def work(img_d):
+    def work(job):
+        img_d, dr = job
         if not hasattr(local, "stream"):
             local.stream = torch.cuda.Stream(device=img_d.device)
             local.stream.wait_stream(caller)
         with torch.cuda.stream(local.stream):
             fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
-                             path, seed=seed)
+                             path, seed=seed, draws=dr)
             out = then(fit) if then is not None else fit
             done = torch.cuda.Event()
             done.record(local.stream)
         return out, done
 
+    jobs = list(zip(images, draws if draws is not None else [None] * len(images)))
     if in_flight <= 1 or len(images) <= 1:
         results = []
-        for img_d in images:
-            if seed is not None:
-                torch.manual_seed(seed)
-            fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg, path)
+        for img_d, dr in jobs:
+            fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg, path,
+                             seed=seed, draws=dr)
             results.append(then(fit) if then is not None else fit)
         return results
     with ThreadPoolExecutor(max_workers=in_flight) as pool:
-        pairs = list(pool.map(work, images))
+        pairs = list(pool.map(work, jobs))
     for _, done in pairs:
         caller.wait_event(done)
     return [out for out, _ in pairs]
@@ -197,23 +224,11 @@ def apply_device(geom, net, msb_d, params_d, path=ops.PATH_AUTO, ws=None, want_y
     return ops.decode_fused(geom, net, msb_d, params_d, want_y=want_y, path=path, ws=ws)
 
 
-def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, host_msb=True):
-    """Host-array front end of fit_device(): img numpy uint16 [C,H,W] or [H,W] -> FitResult.
-    host_msb=False leaves the MSB plane in HBM only (the encoder codes it there)."""
+def _host_result(fit, epochs, seconds, host_msb):
+    """DeviceFit -> FitResult (one host sync: the evaluation log)."""
     res = FitResult()
-    t0 = time.time()
-    img = np.ascontiguousarray(img, dtype=np.uint16)
-    if img.ndim == 2:
-        img = img[None]
-    C, H, W = img.shape
-    img_d = ops.to_device_u16(img, torch.device(device))
-    res.seconds["upload"] = time.time() - t0
-    t1 = time.time()
-    fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
-                     path, keep_losses, perm_workers)
-    mse_host = fit.mse_log.cpu().numpy()                                  # the one sync of the fit
-    res.seconds["fit"] = time.time() - t1
+    res.seconds = dict(seconds)
+    mse_host = fit.mse_log.cpu().numpy()
     if epochs == 1:
         res.best_epoch = 1
     for e in fit.evaluated:
@@ -226,9 +241,47 @@ def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_d
         msb = ops.from_device_u16(fit.msb)
         res.msb = msb.astype(np.uint16) if fit.msb_max > 255 else msb.astype(np.uint8)   # LBDRNdataset.py:100
     res.msb_max = fit.msb_max
+    C, H, W = fit.msb.shape
     res.n_feature, res.channels, res.n_subpixels = fit.geom.F, C, H * W * C
     res.losses = fit.losses
     return res
+
+
+def _as_planes(img):
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    return img[None] if img.ndim == 2 else img
+
+
+def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
+              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, host_msb=True, draws=None):
+    """Host-array front end of fit_device(): img numpy uint16 [C,H,W] or [H,W] -> FitResult.
+    host_msb=False leaves the MSB plane in HBM only (the encoder codes it there)."""
+    t0 = time.time()
+    img_d = ops.to_device_u16(_as_planes(img), torch.device(device))
+    t1 = time.time()
+    fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
+                     path, keep_losses, perm_workers, draws=draws)
+    res = _host_result(fit, epochs, {"upload": t1 - t0}, host_msb)
+    res.seconds["fit"] = time.time() - t1
+    return res
+
+
+def fit_images(imgs, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
+               device="cuda:0", path=ops.PATH_AUTO, host_msb=True, draws=None, seed=None, in_flight=2):
+    """fit_image for several rasters with `in_flight` of them progressing at a time on the GPU (fit_many).
+    Either every fit seeds itself (`seed`: independent images, one encode.py invocation each in the reference)
+    or the caller brings the draws it made in order (`draws`: the tiles of one image, ref encode.py:231-262)."""
+    t0 = time.time()
+    dev = torch.device(device)
+    tiles = [ops.to_device_u16(_as_planes(img), dev) for img in imgs]
+    t1 = time.time()
+    fits = fit_many(tiles, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg, path,
+                    seed=seed, in_flight=in_flight, draws=draws)
+    results = [_host_result(fit, epochs, {"upload": (t1 - t0) / max(len(imgs), 1)}, host_msb) for fit in fits]
+    per_tile = (time.time() - t1) / max(len(imgs), 1)
+    for res in results:
+        res.seconds["fit"] = per_tile          # wall time per tile with the others in flight
+    return results
 
 
 def apply_image(base, params, K, D, base_channel, num_layers, cfg=None, device="cuda:0",

@@ -36,6 +36,17 @@ def epoch_plan(epochs, val_duration):
     return plan
 
 
+def draw_pass_seeds(plan):
+    """One DataLoader iterator per pass of the plan, in order (every pass consumes two draws); returns the
+    sampler seeds of the training passes."""
+    seeds = []
+    for kind, _ in plan:
+        seed = draw_iterator_seed()
+        if kind == "train":
+            seeds.append(seed)
+    return seeds
+
+
 class DevicePermutationStream:
     """Same draws as PermutationStream; the permutations are computed on the GPU by lbdrn_randperm (the
     exact torch.randperm sequences).  The MT19937 recurrence is serial (5 ms for 4 M words, whatever the
@@ -43,15 +54,14 @@ class DevicePermutationStream:
     alone, then all the others -- and the training stream only waits for the batch it needs: the first
     wait hides behind the row-matrix build, the second behind epoch 1."""
 
-    def __init__(self, n, epochs, val_duration, device):
+    def __init__(self, n, epochs, val_duration, device, train_seeds=None):
+        """train_seeds: the sampler seeds of the training passes when they were drawn earlier
+        (codec.draw_fit); None = draw them now from the global generator."""
         from . import ops
         self.plan = epoch_plan(epochs, val_duration)
-        seeds, order = [], []
-        for kind, e in self.plan:
-            seed = draw_iterator_seed()
-            if kind == "train":
-                order.append(e)
-                seeds.append(seed)
+        order = [e for kind, e in self.plan if kind == "train"]
+        seeds = list(train_seeds) if train_seeds is not None else draw_pass_seeds(self.plan)
+        assert len(seeds) == len(order)
         self.seeds = dict(zip(order, seeds))
         self._row = {e: i for i, e in enumerate(order)}
         main = torch.cuda.current_stream(device)

@@ -1,7 +1,7 @@
 """Host logic of the multi-GPU CLIs on CPU (gloo, world_size 2): tile-sharded encode.py / decode.py give the
 files of the serial run, the RNG replay that makes this possible, the sweep's job dealing and the results
-CSV.  The GPU fit itself is replaced by a stand-in that draws from the global generator exactly like a fit
-does (codec.skip_fit_rng) -- what is under test here is everything around it."""
+CSV.  The GPU fits themselves are replaced by a stand-in whose output depends on the random draws made for each
+tile (codec.draw_fit) -- what is under test here is everything around them."""
 import hashlib
 import os
 import re
@@ -35,17 +35,19 @@ def test_skip_fit_rng_consumes_what_a_fit_consumes():
         assert torch.equal(torch.get_rng_state(), after_fit), (epochs, vd)
 
 
-def _stub_train(args, img=None):
-    """Stands where encode.train stands: same generator draws as a fit, payloads that depend on the tile
-    and on the generator state the fit started from."""
+def _stub_train_tiles(args, tiles, draws):
+    """Stands where encode.train_tiles stands (the GPU fits): one result per tile that depends on the tile's
+    pixels and on the draws made for it -- so a wrong draw order on any rank changes the payload."""
+    out = []
+    for (path, img), dr in zip(tiles, draws):
+        h = hashlib.sha256(dr.params.numpy().tobytes() + repr(dr.train_seeds).encode()).digest()
+        out.append((h + hashlib.sha256(img.tobytes()).digest(), img.tobytes()[: 50 + img.shape[2]]))
+    return out
+
+
+def _stub_report(args, res):
     import logger
-    from lbdrn_hip import codec
-    from lbdrn_hip.features import FeatCfg
-    state = hashlib.sha256(torch.get_rng_state().numpy().tobytes()).digest()
-    codec.skip_fit_rng(FeatCfg.from_constants().feature_dim(img.shape[0], args.D), args.base_channel,
-                       img.shape[0], args.num_layers, args.epochs, args.val_duration)
-    nn = state + hashlib.sha256(img.tobytes()).digest()
-    base = img.tobytes()[: 50 + img.shape[2]]
+    nn, base = res
     logger.log.info(f"nn: {len(nn)} bytes, bpsp=0.5")
     logger.log.info(f"MSB: {len(base)} bytes: bpsp=0.25")
     return nn, base
@@ -59,7 +61,7 @@ def _encode_worker(rank, world, port, src, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     import encode
-    encode.train = _stub_train
+    encode.train_tiles, encode.report_and_pack = _stub_train_tiles, _stub_report
     rc = encode.main(["-i", src, "-o", out_dir, "-sr", "3", "-K", "4", "-e", "2", "-bs", "64"])
     assert rc == 0
 
@@ -85,7 +87,8 @@ def test_tile_sharded_encode_equals_serial(tmp_path, monkeypatch):
     rng = np.random.default_rng(4)
     src = str(tmp_path / "scene.npy")
     np.save(src, rng.integers(0, 9000, (2, 31, 40)).astype(np.uint16))
-    monkeypatch.setattr(encode, "train", _stub_train)
+    monkeypatch.setattr(encode, "train_tiles", _stub_train_tiles)
+    monkeypatch.setattr(encode, "report_and_pack", _stub_report)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
     assert encode.main(["-i", src, "-o", str(tmp_path / "serial"), "-sr", "3", "-K", "4", "-e", "2", "-bs", "64"]) == 0

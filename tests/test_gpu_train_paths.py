@@ -212,6 +212,10 @@ def test_tiles_sharded_over_two_ranks_equal_the_serial_run(dev, tmp_path):
     sub = "scene_r3_K4_bc64_nl2_D1_prec16_lr0.001_bs96_e3"
     a, b = (tmp_path / "one" / sub / "scene.bin").read_bytes(), (tmp_path / "two" / sub / "scene.bin").read_bytes()
     assert a == b
+    # ... and of the run that fits the tiles strictly one after another (the default keeps two in flight)
+    subprocess.run([sys.executable, os.path.join(pkg, "encode.py"), "-i", str(src), "-o", str(tmp_path / "seq")] + flags,
+                   check=True, env=dict(env, LBDRN_IN_FLIGHT="1"), capture_output=True)
+    assert (tmp_path / "seq" / sub / "scene.bin").read_bytes() == a
     subprocess.run([sys.executable, os.path.join(pkg, "decode.py"), "-i", str(tmp_path / "one" / sub / "scene.bin"),
                     "-org", str(src)], check=True, env=env, capture_output=True)
     subprocess.run(run2 + [os.path.join(pkg, "decode.py"), "-i", str(tmp_path / "two" / sub / "scene.bin"), "-org", str(src)],
