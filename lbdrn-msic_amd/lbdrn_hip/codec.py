@@ -14,7 +14,7 @@ import torch
 from . import ops
 from .features import FeatCfg
 from .model import LBDRNModel
-from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, draw_iterator_seed, draw_pass_seeds, epoch_plan
+from .sampler import DevicePermutationStream, GPU_RANDPERM_MAX, draw_pass_seeds, epoch_plan
 
 
 def lr_schedule(lr, epochs):
@@ -91,7 +91,7 @@ _RNG_LOCK = threading.Lock()   # the global torch CPU generator is one per proce
 
 
 def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1,
-               cfg=None, path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, seed=None, draws=None):
+               cfg=None, path=ops.PATH_AUTO, keep_losses=False, seed=None, draws=None):
     """Fit one image that already sits in HBM (img_d: [C,H,W] uint16 bits in int16 storage), on the
     calling thread's current stream.
 
@@ -253,14 +253,14 @@ def _as_planes(img):
 
 
 def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, perm_workers=4, host_msb=True, draws=None):
+              device="cuda:0", path=ops.PATH_AUTO, keep_losses=False, host_msb=True, draws=None):
     """Host-array front end of fit_device(): img numpy uint16 [C,H,W] or [H,W] -> FitResult.
     host_msb=False leaves the MSB plane in HBM only (the encoder codes it there)."""
     t0 = time.time()
     img_d = ops.to_device_u16(_as_planes(img), torch.device(device))
     t1 = time.time()
     fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
-                     path, keep_losses, perm_workers, draws=draws)
+                     path, keep_losses, draws=draws)
     res = _host_result(fit, epochs, {"upload": t1 - t0}, host_msb)
     res.seconds["fit"] = time.time() - t1
     return res
