@@ -162,7 +162,8 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
 def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
              path=ops.PATH_AUTO, seed=19920517, in_flight=2, then=None, draws=None):
     """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time, each on
-    its own stream and host thread; returns [then(fit) or fit, ...] in input order.
+    its own stream and host thread (in_flight=None: 2, or 4 when the minibatches are too small to fill the
+    GPU); returns [then(fit) or fit, ...] in input order.
 
     Why: one fit is a strict chain of short dependent kernels (train 19 us -> reduce/Adam 5 us -> train ...),
     so ramp, drain and the kernel boundaries of one image leave the chip idle a quarter of the time; a second
@@ -172,6 +173,11 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
     coding, ...).  `draws`: one FitDraws per image instead of `seed` (the tiles of one image, whose draws the
     caller made in tile order).  Returns after all streams have been joined to the caller's current stream."""
+    if in_flight is None:
+        # a minibatch of >= 8192 rows puts a training workgroup on every CU: two chains saturate the GPU, more add
+        # nothing; smaller minibatches (small tiles) leave CUs free for further chains
+        rows = min(batch_size, min(int(t.shape[1]) * int(t.shape[2]) for t in images)) if images else batch_size
+        in_flight = 2 if rows >= 8192 else 4
     if draws is not None:
         seed = None
         if len(draws) != len(images):
