@@ -192,6 +192,29 @@ def test_train_steps_match_reference_fixture(golden, dev):
     np.testing.assert_allclose(v.cpu().numpy(), T["exp_avg_sq"], rtol=0, atol=1e-5 * np.abs(T["exp_avg_sq"]).max())
 
 
+def test_other_widths_match_reference_fixture(golden, dev):
+    """bc=256 (BASELINE configs[2]) and nl in {1, 3}: HIP forward within 3e-6 of the reference model's, and
+    three teacher-forced bc=256 updates within the training tolerance of torch autograd + Adam."""
+    G = golden["wide_net"]
+    x, t = torch.from_numpy(G["x"]).to(dev), torch.from_numpy(G["t"]).to(dev)
+    for tag, bc, nl in (("bc256_nl2", 256, 2), ("bc64_nl3", 64, 3), ("bc128_nl1", 128, 1)):
+        y = ops.forward(ops.make_net(200, bc, 8, nl), torch.from_numpy(G[tag + "/params"]).to(dev), x)
+        np.testing.assert_allclose(y.cpu().numpy(), G[tag + "/y"], rtol=3e-6, atol=3e-7)
+    net = ops.make_net(200, 256, 8, 2)
+    p = torch.from_numpy(G["train256/params0"].copy()).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for s in range(3):
+        b = torch.from_numpy(G["train256/batches"][s]).to(dev)
+        loss, g = ops.train_step(net, x[b], t[b], p, m, v, s + 1, 1e-3)
+        ref = float(G[f"train256/step{s}/loss"])
+        assert abs(float(loss.item()) - ref) <= RTOL_TRAIN * ref
+        if s == 0:
+            gr = G["train256/step0/grads"]
+            assert np.linalg.norm(g.cpu().numpy() - gr) <= 1e-5 * np.linalg.norm(gr)
+    pr = G["train256/params_final"]
+    assert np.linalg.norm(p.cpu().numpy() - pr) <= 2e-5 * np.linalg.norm(pr)
+
+
 @pytest.mark.parametrize("F,bc,C,nl,B", [(200, 64, 8, 2, 300), (18, 16, 3, 3, 64), (27, 32, 3, 1, 1000),
                                          (200, 256, 8, 2, 257)])  # last: BASELINE config 3 shape
 def test_train_step_vs_oracle(dev, F, bc, C, nl, B):
