@@ -202,3 +202,29 @@ def test_torch_port_forms_agree_and_fit_something():
     import oracle as O
     rec_o = O.decode(a["msb"], 5, 1, O.FeatCfg(), a["params"], 16, 2)
     assert (rec_o != rec).mean() < 1e-3   # canonical arithmetic vs torch: boundary flips only
+
+
+def test_tile_windows_equal_the_reference_split_and_merge(golden):
+    """The windows the reference's split_image cuts and merge_tiles pastes (tests/golden/make_golden_tiles.py
+    ran them with a recording gdal stand-in) for six sizes / split ratios, last row and column ragged."""
+    from LBDRNdataset import tile_windows
+    G = golden["tiles"]
+    assert len(G.files) == 6
+    for key in G.files:
+        w, h, sr = (int(x[1:]) if x[0] in "wh" else int(x[2:]) for x in key.split("_"))
+        assert [tuple(int(v) for v in row) for row in G[key]] == list(tile_windows(w, h, sr)), key
+
+
+def test_results_summary_parser_equals_the_reference(tmp_path):
+    """extract_metrics on four log files against what the reference's results_summary.extract_metrics returned
+    for the same texts (tests/golden/make_golden_summary.py): last record wins, integers without a decimal
+    point are not matched, missing records stay missing."""
+    import json
+    import results_summary as R
+    with open(os.path.join(ROOT, "tests", "golden", "summary.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 4
+    for name, case in cases.items():
+        path = tmp_path / f"{name}.txt"
+        path.write_text(case["log"])
+        assert R.extract_metrics(str(path)) == case["metrics"], name
