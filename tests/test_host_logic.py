@@ -228,3 +228,22 @@ def test_results_summary_parser_equals_the_reference(tmp_path):
         path = tmp_path / f"{name}.txt"
         path.write_text(case["log"])
         assert R.extract_metrics(str(path)) == case["metrics"], name
+
+
+def test_constants_and_log_record_layout_equal_the_reference(tmp_path):
+    """constants.py switches and the '[timestamp] message' layout of a logged record, against what the
+    reference's own constants.py / logger.py produced (tests/golden/make_golden_misc.py)."""
+    import json
+    import re
+    import constants as C
+    import logger as L
+    with open(os.path.join(ROOT, "tests", "golden", "misc.json")) as f:
+        G = json.load(f)
+    assert {k: getattr(C, k) for k in dir(C) if k.isupper()} == G["constants"]
+    L.create_logger(str(tmp_path / "sub" / "dir"), "run.txt", log_file_only=True)
+    L.log.info("MSE: 1.25")
+    L.log.info(f"Total size: {1234} bytes, bpsp={0.5}")
+    L.destroy_logger()
+    lines = (tmp_path / "sub" / "dir" / "run.txt").read_text().splitlines()
+    layout = [re.sub(r"\d", "d", re.match(r"^\[[^\]]*\]", ln).group(0)) + ln[ln.index("]") + 1:] for ln in lines]
+    assert layout == G["log_layout"]
