@@ -281,3 +281,35 @@ def test_train_epoch_is_bitwise_reproducible(dev):
         ops.train_epoch(geom, net, ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev), perm, bs, p, m, v, 0, 1e-3)
         outs.append(p.cpu().numpy())
     assert np.array_equal(_bits(outs[0]), _bits(outs[1]))
+
+
+def test_drop_in_process_and_dataset_equal_reference_fixture(golden, dev, tmp_path, monkeypatch):
+    """The drop-in LBDRNdataset.process() / LBDRNDataset (the reference's own entry points, ref
+    LBDRNdataset.py:92-155) on every fixture case: feature and label matrices bit-identical to what the
+    reference's process() returned, the written MSB raster is img >> K with the reference's dtype rule, and
+    the Dataset exposes the same attributes and items."""
+    import argparse
+    import constants
+    import LBDRNdataset as DS
+    from lbdrn_hip import raster_io
+    G = golden["features"]
+    names = sorted({k.split("/")[0] for k in G.files})
+    assert len(names) >= 10
+    for name in names:
+        img, K, D = G[name + "/img"], int(G[name + "/K"]), int(G[name + "/D"])
+        for flag, val in zip(("USE_COORDINATES", "EMBEDDING", "USE_COLORS", "RELATIVE"), G[name + "/flags"]):
+            monkeypatch.setattr(constants, flag, bool(val))
+        src = str(tmp_path / f"{name}.npy")
+        np.save(src, img)
+        f, l = DS.process(src, K, D, str(tmp_path / f"{name}_base.tif"))
+        assert f.dtype == np.float32 and np.array_equal(f.view(np.int32), G[name + "/features"].view(np.int32)), name
+        assert np.array_equal(l.view(np.int32), G[name + "/labels"].view(np.int32)), name
+        base = raster_io.read_raster(str(tmp_path / f"{name}_base.tif")).reshape(img.shape)
+        assert np.array_equal(base, img >> K), name
+        assert base.dtype == (np.uint16 if int((img >> K).max()) > 255 else np.uint8), name   # LBDRNdataset.py:100
+        ds = DS.LBDRNDataset(argparse.Namespace(path=src, output_dir=str(tmp_path), K=K, D=D))
+        assert (ds.n_pixels, ds.n_feature, ds.channels, ds.n_subpixels) == \
+            (f.shape[0], f.shape[1], l.shape[1], f.shape[0] * l.shape[1]), name
+        assert len(ds) == f.shape[0]
+        x7, t7 = ds[min(7, len(ds) - 1)]
+        assert torch.equal(x7, torch.from_numpy(f[min(7, len(ds) - 1)])) and t7.dtype == torch.float32
