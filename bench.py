@@ -125,8 +125,8 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
                     "timing": "HIP events over one 512-step epoch of ONE fit on the launch stream, and over one with the "
                               "reduce launch doubled; kernel_us = step - reduce, inside the real launch sequence. "
                               "rocprofv3 agrees on the same one-fit sequence (profiles/r01_final_kernel_stats_one_in_flight.csv: "
-                              "19.5 us); with two fits in flight (the timed region) a trace's per-launch durations also "
-                              "contain the other fit's co-running reduce kernels (..._two_in_flight.csv: 24.2 us)"})
+                              "20.0 us); with two fits in flight (the timed region) a trace's per-launch durations also "
+                              "contain the other fit's co-running reduce kernels (..._two_in_flight.csv: 24.4 us)"})
     else:  # shape without an MFMA train kernel: the generic step is many launches
         t_k = t_epoch / nsteps
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})

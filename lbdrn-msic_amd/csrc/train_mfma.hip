@@ -49,7 +49,10 @@ constexpr int TBC = 64;      // hidden width this kernel is built for
 constexpr int HP = 68;       // [sample][64] rows: 17 chunks of 16 B
 constexpr int TP = 36;       // [unit][32 samples] rows: 9 chunks of 16 B
 constexpr int OP = 20;       // [sample][16 channel slots] rows: 5 chunks
-constexpr int RED_SLICES = 32;  // workgroup slices per reduce block
+constexpr int RED_SLICES = 8;   // workgroup slices per reduce block: 8 x 32 float4 lanes = 512 B per slab and block.
+                                // A/B (scripts/ab_inflight.py): 32 slices are 2.8 ms per tile faster for one fit at a time,
+                                // 8 slices 5 ms faster with two fits in flight (fewer, longer blocks disturb the other
+                                // fit's train kernel less); 4 and 64 lose both ways
 constexpr int RED_LANES = 256 / RED_SLICES;  // float4 lanes per reduce block
 constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample tile st = 0..1)
 
@@ -95,7 +98,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.sl_hid = s; s += (net.nl - 1) * 16 * 256;
     p.sl_out = s; s += 4 * 256;
     p.sl_bias = s; s += net.nl * TBC + 16;
-    p.slab_floats = (s + 63) / 64 * 64;  // multiple of 4*RED_LANES
+    p.slab_floats = (s + 127) / 128 * 128;  // multiple of 4*RED_LANES
     int f = 0;
     p.lds_x = f; f += TB * p.XP;
     p.lds_xt = f; f += 16 * p.NT0 * TP;
@@ -324,8 +327,8 @@ __global__ void __launch_bounds__(256)
 // g[e] = sum over workgroups of slab[wg][e], in a fixed order (slices of nwg/RED_SLICES slabs summed in
 // index order, then the slices in index order: bitwise reproducible, no atomics); torch Adam
 // (torch/optim/adam.py single-tensor path: lerp_, mul_/addcmul_, addcdiv_); refresh the fragment copy.
-// Block = RED_LANES float4 lanes (32 slab elements) x RED_SLICES workgroup slices; the final sum over
-// slices and the update are spread over 32 threads, one slab element each.
+// Block = RED_LANES float4 lanes (4*RED_LANES slab elements) x RED_SLICES workgroup slices; the final sum over
+// slices and the update are spread over 4*RED_LANES threads, one slab element each.
 __global__ void __launch_bounds__(256)
     k_reduce_adam(const float* __restrict__ slabs, int nwg, int slab_floats, const int2* __restrict__ map,
                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
