@@ -167,7 +167,7 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
 
     Why: one fit is a strict chain of short dependent kernels (train 19 us -> reduce/Adam 5 us -> train ...),
     so ramp, drain and the kernel boundaries of one image leave the chip idle a quarter of the time; a second
-    independent chain fills those holes (measured: 156 -> 116 ms per 8 x 2048^2 tile).  Images are independent
+    independent chain fills those holes (measured: 158 -> 108 ms per 8 x 2048^2 tile).  Images are independent
     fits and every fit seeds the generator itself (`seed`, what each encode.py invocation does,
     ref encode.py:200-205), so results are bit-identical to fitting them one after another.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
