@@ -351,12 +351,12 @@ __global__ void __launch_bounds__(256)
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* src = slabs + base + 4 * l16;
     int w = w0;
-    for (; w + 8 <= w1; w += 8) {  // eight loads in flight, added in index order
-        float4 t[8];
+    for (; w + 16 <= w1; w += 16) {  // sixteen loads in flight, added in index order (8: +0.9 ms per tile, 32: +5 ms)
+        float4 t[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u) * slab_floats);
+        for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(w + u) * slab_floats);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+        for (int u = 0; u < 16; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
     }
     for (; w < w1; ++w) {
         float4 t = *reinterpret_cast<const float4*>(src + (size_t)w * slab_floats);
