@@ -88,6 +88,8 @@ class DeviceFit:
 
 
 _RNG_LOCK = threading.Lock()   # the global torch CPU generator is one per process
+_POOL_LOCK = threading.Lock()
+_FIT_STREAMS = {}               # device -> streams the fits in flight run on
 
 
 def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1,
@@ -187,11 +189,20 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
                          "they share one generator")
     caller = torch.cuda.current_stream(images[0].device) if images else None
     local = threading.local()
+    taken = []   # worker index -> stream of the process-wide pool
 
     def work(job):
         img_d, dr = job
         if not hasattr(local, "stream"):
-            local.stream = torch.cuda.Stream(device=img_d.device)
+            # streams are kept for the life of the process: torch's caching allocator pools memory per stream,
+            # so a fresh stream per call would send every fit's 3.5 GB workspace back to hipMalloc
+            with _POOL_LOCK:
+                pool_ = _FIT_STREAMS.setdefault(img_d.device, [])
+                k = len(taken)
+                if k >= len(pool_):
+                    pool_.append(torch.cuda.Stream(device=img_d.device))
+                taken.append(pool_[k])
+                local.stream = pool_[k]
             local.stream.wait_stream(caller)
         with torch.cuda.stream(local.stream):
             fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
