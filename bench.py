@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "lbdrn-msic_amd"))
+# the fits in flight, the permutation side stream and torch's own streams should each get a hardware queue of
+# their own (the runtime's default is four per process; streams that share one run one after the other)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
