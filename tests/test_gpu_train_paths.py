@@ -353,3 +353,30 @@ def test_fits_in_flight_together_equal_fits_one_by_one(dev):
         assert torch.equal((rec.to(torch.int32) & 0xFFFF) >> 5, (img_d.to(torch.int32) & 0xFFFF) >> 5)
     with pytest.raises(ValueError):
         codec.fit_many(imgs, *args, seed=None, in_flight=2)
+
+
+def test_bench_prints_one_json_line_with_the_contract_keys(dev):
+    """bench.py on a small tile (same code path as the full-size run): exactly one JSON line on stdout with the
+    driver's keys, the roofline and cpu_baseline objects, and values of the right kind."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--height", "192", "--width", "256", "-bs", "2048", "-e", "3", "--cpu-sample", "48"],
+                         check=True, env=env, capture_output=True, text=True, timeout=900).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["value"] > 0 and abs(d["value"] - 192 * 256 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-3 * d["value"] + 1e-3
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
