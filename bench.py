@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the LBDRN per-image encode+decode hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, one per GPU, over RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one synthetic tile: the fused fit (bit split, 10 epochs of
@@ -36,7 +36,8 @@ SEED = 19920517  # ref encode.py:169
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=4)
+    p.add_argument("--steps", type=int, default=None,
+                   help="timed tiles per GPU (default 4; 8 at --gpus 8 = the 64-tile job of BASELINE.json configs[3])")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--height", type=int, default=2048)
     p.add_argument("--width", type=int, default=2048)
@@ -54,8 +55,13 @@ def parse():
     p.add_argument("--in-flight", type=int, default=2,
                    help="tiles progressing at a time on each GPU (independent fits on their own streams)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample", type=int, default=192, help="side of the CPU-baseline crop")
-    return p.parse_args()
+    p.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline crop")
+    p.add_argument("--cpu-epochs", type=int, default=1,
+                   help="epochs of the recipe the CPU baseline runs on its crop (scaled to the full recipe)")
+    a = p.parse_args()
+    if a.steps is None:
+        a.steps = 8 if a.gpus == 8 else 4
+    return a
 
 
 def feat_cfg(a):
@@ -151,47 +157,131 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
 
 
 def cpu_baseline(a):
-    """The torch-CPU restatement of the reference loop (oracle/torch_port.py) on a crop of the same
-    synthetic tile, sized for ~10-30 s.  Form A (the headline): map-style dataset + DataLoader + per-step
-    update + concatenating whole-image metric, i.e. the reference's cost structure; form B beside it:
-    index_select minibatches + streaming MSE (math only).  GDAL / fpzip / file I/O excluded from both."""
+    """The torch-CPU restatement of the reference loop (oracle/torch_port.py) on a crop of the same synthetic
+    tile, bounded to ~10-30 s: `--cpu-epochs` epochs of the recipe (each = one shuffled training pass + one
+    whole-image evaluation pass, identical work every epoch) on a `--cpu-sample`^2 crop, scaled linearly to the
+    full `-e` epochs.  Form A (the headline): map-style dataset + DataLoader(shuffle, bs,
+    num_workers=min(32, cores)) + per-step Adam + concatenating whole-image metric, i.e. the reference's cost
+    structure; form B beside it: index_select minibatches + streaming MSE (math only).  GDAL / fpzip / file I/O
+    excluded from both."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     import torch_port as TP
     from lbdrn_hip.synth import synthetic_tile
-    side = a.cpu_sample
+    side = min(a.cpu_sample, a.height, a.width)
     img = synthetic_tile(0, a.bands, a.height, a.width)[:, :side, :side].copy()
     ocfg = O.FeatCfg(use_coordinates=a.coords_embedding, embedding=a.coords_embedding)
+    ep = max(2, min(a.cpu_epochs, a.epochs)) if a.epochs > 1 else 1
+    workers = min(32, os.cpu_count() or 1)
     out = {}
     for form, faithful in (("A", True), ("B", False)):
         torch.manual_seed(SEED)
         t0 = time.time()
-        r = TP.fit(img, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=ocfg, faithful=faithful)
-        t_enc = time.time() - t0
+        r = TP.fit(img, a.K, a.D, a.bc, a.nl, a.lr, a.bs, ep, cfg=ocfg, faithful=faithful,
+                   num_workers=workers if faithful else 0)
+        t_call = time.time() - t0
+        t_loop = r["seconds"]                                # the epochs; the rest is the once-per-image feature build
+        t_enc = (t_call - t_loop) + t_loop * (a.epochs / ep)
         t0 = time.time()
         TP.apply(r["msb"], r["params"], a.K, a.D, a.bc, a.nl, cfg=ocfg)
         t_dec = time.time() - t0
-        out[form] = (side * side / (t_enc + t_dec) / 1e6, t_enc, t_dec)
+        out[form] = (side * side / (t_enc + t_dec) / 1e6, t_enc, t_dec, t_call)
     return {"value": round(out["A"][0], 6), "unit": "Mpixels/s", "cores": torch.get_num_threads(),
-            "host_cpus": os.cpu_count(), "kind": "port",
+            "host_cpus": os.cpu_count(), "kind": "port", "loader_workers": workers,
             "vectorised_form_B": round(out["B"][0], 6),
-            "sample": f"{side}x{side}x{a.bands} crop of tile 0, full recipe (e={a.epochs}, bs={a.bs}); form A = "
-                      f"DataLoader(num_workers=0) + per-step Adam + concatenating eval metric: encode "
-                      f"{out['A'][1]:.1f}s decode {out['A'][2]:.1f}s; form B = index_select batches + streaming MSE: "
-                      f"encode {out['B'][1]:.1f}s decode {out['B'][2]:.1f}s"}
+            "sample": f"{side}x{side}x{a.bands} crop of tile 0 ({(side * side + a.bs - 1) // a.bs} minibatches per pass), "
+                      f"{ep} of {a.epochs} epochs measured (bs={a.bs}; every epoch = one training pass + one evaluation "
+                      f"pass) and scaled to {a.epochs}; form A = DataLoader(num_workers={workers}) + per-step Adam + "
+                      f"concatenating eval metric: measured {out['A'][3]:.1f}s -> encode {out['A'][1]:.1f}s decode "
+                      f"{out['A'][2]:.1f}s; form B = index_select batches + streaming MSE: measured {out['B'][3]:.1f}s "
+                      f"-> encode {out['B'][1]:.1f}s decode {out['B'][2]:.1f}s"}
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks, one per GPU, BEFORE this process makes
+    any GPU call (it never does), relay rank 0's JSON line, fail if any rank fails.  Same environment contract as
+    torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("LBDRN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    if backend == "nccl" and ndev < a.gpus and os.environ.get("LBDRN_BENCH_DRYRUN") != "1":
+        print(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as line0:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=line0 if r == 0 else subprocess.DEVNULL))
+        # a rank that dies leaves the others waiting in a rendezvous or a barrier: stop them (by PID) right away
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+            time.sleep(0.1)
+        codes = [p.wait() for p in procs]
+        line0.seek(0)
+        for ln in line0.read().splitlines():      # the JSON line only (gloo announces its connections on stdout)
+            if ln.startswith("{"):
+                print(ln)
+            elif ln.strip():
+                print(ln, file=sys.stderr)
+        sys.stdout.flush()
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def dry_run(a, rank, world):
+    """LBDRN_BENCH_DRYRUN=1: the launcher and the exchange only (gloo, no GPU call) -- what the CPU test of
+    `--gpus 2` runs; prints the shape of the bench line with no measurement in it."""
+    from lbdrn_hip import shard
+    if world > 1:
+        dist.init_process_group("gloo")
+    mine = shard.assign((a.warmup + a.steps) * world, rank, world)
+    records = shard.gather_records([[float(i), 0.0, 0.0] for i in mine[a.warmup:]], 3)
+    elapsed = shard.max_over_ranks(1.0 + rank)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "records": records,
+                          "max_over_ranks": elapsed}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
     a = parse()
+    launched = "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not launched:
+        return launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        return 2
+    if os.environ.get("LBDRN_BENCH_DRYRUN") == "1":
+        return dry_run(a, rank, world)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (liblbdrn_hip has no CPU path)", file=sys.stderr)
         return 2
     # one process per GPU.  LBDRN_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks
     # (ranks then share devices round-robin and the three scalars per rank travel over gloo instead of RCCL)
     backend = os.environ.get("LBDRN_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU of its own ({torch.cuda.device_count()} visible)", file=sys.stderr)
+        return 2
     local = local % torch.cuda.device_count() if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -224,15 +314,28 @@ def main():
     t0 = time.perf_counter()
     done = run_images(codec, ops, tiles[a.warmup:], a, path)
     barrier()
-    last = done[-1] + (tiles[-1],)
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, xdev)
 
-    # per-image metric record of the last tile (after the clock): MSE / PSNR of the reconstruction
-    fit, rec, img_d = last
-    diff = (img_d.view(torch.int16).to(torch.int32) & 0xFFFF).float() - (rec.to(torch.int32) & 0xFFFF).float()
-    mse = float((diff * diff).mean().item())
-    # [image index, reconstruction MSE, best evaluation MSE]: the only data the ranks exchange
-    records = shard.gather_records([[float(mine[-1]), mse, float(fit.mse_log[:, 0].min().item())]], 3, xdev)
+    # per-image metric records (after the clock): [image index, reconstruction MSE, best evaluation MSE] for every
+    # timed tile -- the only data the ranks exchange
+    recs = []
+    for idx, img_d, (fit, rec) in zip(mine[a.warmup:], tiles[a.warmup:], done):
+        diff = (img_d.view(torch.int16).to(torch.int32) & 0xFFFF).float() - (rec.to(torch.int32) & 0xFFFF).float()
+        recs.append([float(idx), float((diff * diff).mean().item()), float(fit.mse_log[:, 0].min().item())])
+    records = shard.gather_records(recs, 3, xdev)
+    fit, rec = done[-1]
+    img_d, mse = tiles[-1], recs[-1][1]
+
+    # one tile alone on the GPU (BASELINE.json configs[1] is "a single tile"): rank 0, after the clock
+    single_ms = None
+    if rank == 0:
+        one = argparse.Namespace(**vars(a))
+        one.in_flight = 1
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        run_images(codec, ops, tiles[-1:], one, path)
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - ts) * 1e3
 
     if rank == 0:
         px = a.height * a.width
@@ -250,6 +353,10 @@ def main():
                        "tiles_per_gpu": a.steps, "tiles_in_flight_per_gpu": min(a.in_flight, a.steps),
                        "warmup_note": "the warm-up tiles run once on each in-flight stream",
                        "parallelism": f"image-sharded x{world}", "path": a.path},
+            "single_tile_ms": round(single_ms, 3),
+            "single_tile_mpixels_per_s": round(px / single_ms / 1e3, 4),
+            "single_tile_note": "one tile alone on one GPU (nothing else in flight), encode fit + truncation + decode; "
+                                "`value` is the throughput with tiles_in_flight_per_gpu independent tiles progressing together",
             "recon_mse_last_tile": round(mse, 4),
             "recon_psnr_last_tile": round(10 * np.log10(10000 ** 2 / max(mse, 1e-12)), 3),
             "records": records,

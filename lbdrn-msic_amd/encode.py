@@ -120,7 +120,7 @@ def main(argv=None, shard_tiles=None):
         shard_tiles = shard.env_world()[1] > 1
     if shard_tiles:
         rank, world, local = shard.init_host_group()
-        DEVICE = shard.device_for(local)
+        DEVICE = shard.bind_device(local)
     if not args.randomness:
         torch.manual_seed(args.seed)
         np.random.seed(args.seed)

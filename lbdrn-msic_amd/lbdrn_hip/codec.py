@@ -252,6 +252,13 @@ def _host_result(fit, epochs, seconds, host_msb):
         res.epoch_mse.append((e, float(mse_host[e - 1, 0]), bool(mse_host[e - 1, 1] > 0)))
         if mse_host[e - 1, 1] > 0:
             res.best_epoch, res.best_mse = e, float(mse_host[e - 1, 0])
+    if epochs > 1 and fit.evaluated and res.best_epoch < 0:
+        # the reference would stop at torch.load of a model.pt that was never saved (ref encode.py:108-122);
+        # writing the initial weights into a bitstream silently is worse than stopping
+        worst = [m for _, m, _ in res.epoch_mse]
+        raise ops._lib.LbdrnError(
+            f"no evaluation pass improved on the initial best MSE of 1e6 (per-epoch MSE {worst}): the fit diverged or "
+            "the input is degenerate (e.g. an all-zero MSB plane gives 0/0 features); no bitstream is written")
     res.params = fit.best_params.cpu().numpy()
     res.msb_device = fit.msb
     if host_msb:

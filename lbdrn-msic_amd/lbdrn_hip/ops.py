@@ -10,8 +10,16 @@ from . import _lib
 from ._lib import Geom, Net, PATH_AUTO, check, lib
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _call(fn, ref, *args):
+    """One C entry point, asynchronous on the current stream of the device `ref` (a tensor or a device) lives on.
+    The library launches on the stream it is handed and sizes its kernels from the thread's current HIP device,
+    so both are taken from the data, never from whatever device happens to be current (one process may hold
+    tensors of several GPUs; torchrun ranks > 0 must not fall back to cuda:0)."""
+    dev = ref.device if isinstance(ref, torch.Tensor) else torch.device(ref)
+    if dev.type != "cuda":
+        raise _lib.LbdrnError("liblbdrn_hip works on device (HBM) tensors only; there is no CPU path in this package")
+    with torch.cuda.device(dev):
+        check(fn(*args, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
 
 def _ptr(t):
@@ -70,7 +78,7 @@ def split_bits(img, K):
     C, H, W = img.shape
     msb = torch.empty_like(img)
     mx = torch.zeros(1, dtype=torch.int32, device=img.device)
-    check(lib().lbdrn_split_bits(_ptr(img), C, H, W, K, _ptr(msb), _ptr(mx), _stream()))
+    _call(lib().lbdrn_split_bits, img, _ptr(img), C, H, W, K, _ptr(msb), _ptr(mx))
     return msb, int(mx.item())
 
 
@@ -83,7 +91,7 @@ def labels(img, K, idx=None):
     out = torch.empty((n, C), dtype=torch.float32, device=img.device)
     if idx is not None:
         idx = idx.to(torch.int64).contiguous()
-    check(lib().lbdrn_labels(_ptr(img), C, H, W, K, _ptr(idx), n, _ptr(out), _stream()))
+    _call(lib().lbdrn_labels, img, _ptr(img), C, H, W, K, _ptr(idx), n, _ptr(out))
     return out
 
 
@@ -95,7 +103,7 @@ def features(geom, msb, idx=None):
     out = torch.empty((n, geom.F), dtype=torch.float32, device=msb.device)
     if idx is not None:
         idx = idx.to(torch.int64).contiguous()
-    check(lib().lbdrn_features(ctypes.byref(geom.c), _ptr(msb), _ptr(idx), n, _ptr(out), _stream()))
+    _call(lib().lbdrn_features, msb, ctypes.byref(geom.c), _ptr(msb), _ptr(idx), n, _ptr(out))
     return out
 
 
@@ -109,8 +117,7 @@ def forward(net, params, x):
     y = torch.empty((B, net.C), dtype=torch.float32, device=x.device)
     nbytes = lib().lbdrn_forward_workspace(ctypes.byref(net), B)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
-    check(lib().lbdrn_forward(ctypes.byref(net), _ptr(params), _ptr(x), B, _ptr(y), _ptr(ws), nbytes,
-                              _stream()))
+    _call(lib().lbdrn_forward, x, ctypes.byref(net), _ptr(params), _ptr(x), B, _ptr(y), _ptr(ws), nbytes)
     return y
 
 
@@ -128,8 +135,8 @@ def decode_fused(geom, net, msb, params, want_y=False, path=PATH_AUTO, ws=None):
     out = torch.empty_like(msb)
     y = torch.empty((geom.H * geom.W, geom.C), dtype=torch.float32, device=msb.device) if want_y else None
     ws = ws or ApplyWorkspace(geom, net, msb.device)
-    check(lib().lbdrn_decode_fused(ctypes.byref(geom.c), ctypes.byref(net), _ptr(msb), _ptr(params),
-                                   _ptr(out), _ptr(y), _ptr(ws.buf), ws.nbytes, path, _stream()))
+    _call(lib().lbdrn_decode_fused, msb, ctypes.byref(geom.c), ctypes.byref(net), _ptr(msb), _ptr(params),
+                                   _ptr(out), _ptr(y), _ptr(ws.buf), ws.nbytes, path)
     return (out, y) if want_y else out
 
 
@@ -141,8 +148,8 @@ def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None):
     params = params.contiguous().float()
     sse = out if out is not None else torch.zeros(1, dtype=torch.float64, device=msb.device)
     ws = ws or ApplyWorkspace(geom, net, msb.device)
-    check(lib().lbdrn_eval_sse(ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
-                               _ptr(params), _ptr(sse), _ptr(ws.buf), ws.nbytes, path, _stream()))
+    _call(lib().lbdrn_eval_sse, msb, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
+                               _ptr(params), _ptr(sse), _ptr(ws.buf), ws.nbytes, path)
     return sse
 
 
@@ -157,9 +164,8 @@ class TrainWorkspace:
 
     def prepare(self, img, msb, path=PATH_AUTO):
         img, msb = _u16(img.contiguous()), _u16(msb.contiguous())
-        check(lib().lbdrn_train_prepare(ctypes.byref(self.geom.c), ctypes.byref(self.net), _ptr(img),
-                                        _ptr(msb), self.batch_size, _ptr(self.buf), self.nbytes, path,
-                                        _stream()))
+        _call(lib().lbdrn_train_prepare, img, ctypes.byref(self.geom.c), ctypes.byref(self.net), _ptr(img),
+                                        _ptr(msb), self.batch_size, _ptr(self.buf), self.nbytes, path)
         self.prepared_for = (img.data_ptr(), path)
         return self
 
@@ -177,10 +183,10 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
         ws = TrainWorkspace(geom, net, batch_size, img.device).prepare(img, msb, path)
     if ws.prepared_for != (img.data_ptr(), path):
         raise _lib.LbdrnError("TrainWorkspace.prepare(img, msb, path) must run once for this image first")
-    check(lib().lbdrn_train_epoch(ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
+    _call(lib().lbdrn_train_epoch, img, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
                                   _ptr(perm), perm.numel(), batch_size, _ptr(params), _ptr(exp_avg),
                                   _ptr(exp_avg_sq), adam_step0, float(lr), _ptr(losses), _ptr(ws.buf),
-                                  ws.nbytes, path, _stream()))
+                                  ws.nbytes, path)
 
 
 def train_profile_mode(mode):
@@ -199,9 +205,9 @@ def train_step(net, x, t, params, exp_avg, exp_avg_sq, adam_step, lr, apply_adam
     g = Geom(net.C, 1, 1, 1, 0, 1, 1, 1, 0, 0, None, None)
     nbytes = lib().lbdrn_train_workspace(ctypes.byref(g), ctypes.byref(net), B)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=x.device)
-    check(lib().lbdrn_train_step(ctypes.byref(net), _ptr(x), _ptr(t), B, _ptr(params), _ptr(exp_avg),
+    _call(lib().lbdrn_train_step, x, ctypes.byref(net), _ptr(x), _ptr(t), B, _ptr(params), _ptr(exp_avg),
                                  _ptr(exp_avg_sq), adam_step, float(lr), int(apply_adam), _ptr(loss),
-                                 _ptr(grads), _ptr(ws), nbytes, _stream()))
+                                 _ptr(grads), _ptr(ws), nbytes)
     return loss, grads
 
 
@@ -216,7 +222,7 @@ def randperm(seeds, n, device):
         arr = (ctypes.c_uint64 * len(chunk))(*[s & 0xFFFFFFFFFFFFFFFF for s in chunk])
         nbytes = lib().lbdrn_randperm_workspace(n, len(chunk))
         ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        check(lib().lbdrn_randperm(arr, len(chunk), n, _ptr(out[c0:]), _ptr(ws), nbytes, _stream()))
+        _call(lib().lbdrn_randperm, out, arr, len(chunk), n, _ptr(out[c0:]), _ptr(ws), nbytes)
     return out[0] if scalar else out
 
 
@@ -230,8 +236,8 @@ def plane_encode(planes):
     body = torch.empty(lib().lbdrn_plane_bound(C, H, W), dtype=torch.uint8, device=dev)
     nbytes = torch.zeros(1, dtype=torch.int64, device=dev)
     ws = torch.empty(max(lib().lbdrn_plane_workspace(C, H, W), 1), dtype=torch.uint8, device=dev)
-    check(lib().lbdrn_plane_encode(_ptr(planes), C, H, W, _ptr(body), body.numel(), _ptr(nbytes), _ptr(ws),
-                                   ws.numel(), _stream()))
+    _call(lib().lbdrn_plane_encode, planes, _ptr(planes), C, H, W, _ptr(body), body.numel(), _ptr(nbytes), _ptr(ws),
+                                   ws.numel())
     return body[:int(nbytes.item())].cpu().numpy().tobytes()
 
 
@@ -241,8 +247,8 @@ def plane_decode(body, C, H, W, device):
     planes = torch.empty((C, H, W), dtype=torch.int16, device=device)
     status = torch.zeros(1, dtype=torch.int32, device=device)
     ws = torch.empty(max(lib().lbdrn_plane_workspace(C, H, W), 1), dtype=torch.uint8, device=device)
-    check(lib().lbdrn_plane_decode(_ptr(raw), raw.numel(), C, H, W, _ptr(planes), _ptr(status), _ptr(ws),
-                                   ws.numel(), _stream()))
+    _call(lib().lbdrn_plane_decode, planes, _ptr(raw), raw.numel(), C, H, W, _ptr(planes), _ptr(status), _ptr(ws),
+                                   ws.numel())
     if int(status.item()):
         raise _lib.LbdrnError("LBB2 payload is inconsistent with its geometry (corrupt or truncated stream)")
     return planes

@@ -32,6 +32,16 @@ def device_for(local_rank):
     return f"cuda:{local_rank % n}" if n else "cuda:0"
 
 
+def bind_device(local_rank):
+    """device_for() and make that GPU the process's current device, once, before any GPU call: every allocation,
+    stream and kernel of this rank then lives on its own GPU (ops._call additionally takes device and stream
+    from the tensors it is handed, so a stray tensor of another GPU cannot pull a launch over to it)."""
+    name = device_for(local_rank)
+    if torch.cuda.device_count():
+        torch.cuda.set_device(torch.device(name))
+    return name
+
+
 def gather_to_root(obj):
     """Every rank's `obj` as a list on rank 0 (None elsewhere); [obj] without a process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

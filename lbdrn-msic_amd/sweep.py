@@ -11,7 +11,7 @@ results_summary.py.
     python sweep.py -o outputs --images a.tif b.tif --k 1 6            # single GPU
 
 The positional form of run.sh is kept too:  sweep.py DEVICE_ID D BC NL LR BS EPOCH SR OUTPUT_DIR
-(DEVICE_ID is ignored: device placement comes from the launcher).
+(run.sh exports HIP_VISIBLE_DEVICES=DEVICE_ID unless NGPU is set; sweep.py itself takes its device from the launcher).
 """
 import argparse
 import os
@@ -81,7 +81,7 @@ def run_point(a, image, K):
 def main(argv=None):
     a = parse(argv)
     rank, world, local = shard.init_host_group()
-    encode.DEVICE = decode.DEVICE = shard.device_for(local)
+    encode.DEVICE = decode.DEVICE = shard.bind_device(local)
     todo = points(a)
     records = []
     for idx in shard.assign(len(todo), rank, world):

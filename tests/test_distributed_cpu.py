@@ -43,3 +43,25 @@ def test_single_process_fallbacks():
     assert shard.assign(5, 0, 1) == [0, 1, 2, 3, 4]
     assert shard.gather_records([[1.0, 2.0]], 2) == [[1.0, 2.0]]
     assert shard.max_over_ranks(3.5) == 3.5
+
+
+def test_bench_gpus_2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks before touching any GPU and
+    relays rank 0's single JSON line (LBDRN_BENCH_DRYRUN: launcher + gloo exchange only, nothing is measured)."""
+    import json
+    import subprocess
+    env = dict(os.environ, LBDRN_BENCH_DRYRUN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         check=True, env=env, capture_output=True, text=True, timeout=300).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["records"]) == 2 * 3
+    assert sorted(r[0] for r in d["records"]) == [2.0, 3.0, 4.0, 5.0, 6.0, 7.0]   # the timed tiles of both ranks
+    assert d["max_over_ranks"] == 2.0
+    # a launcher that started a different number of ranks than --gpus is an error, not a silent n_gpus=1
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "--gpus 2" in bad.stderr
