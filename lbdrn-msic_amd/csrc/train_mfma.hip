@@ -56,6 +56,15 @@ constexpr int RED_SLICES = 8;   // workgroup slices per reduce block: 8 x 32 flo
 constexpr int RED_LANES = 256 / RED_SLICES;  // float4 lanes per reduce block
 constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample tile st = 0..1)
 
+// ---- the wave-local step (k_train_wave, below): 64 samples per workgroup, 4 waves, 16 samples per wave
+constexpr int WB = 64;            // samples per workgroup
+constexpr int WAVE_THREADS = 256;
+constexpr int WHP = 80;           // [sample][64 units] row pitch.  All pitches of this kernel are = 16 (mod 32) floats:
+constexpr int WOP = 16;           //   the weight-gradient operands are read one float per lane, lanes 0-15 along a row
+                                  //   and lane quarters one row apart, so two quarters (one ds_read_b32 group) cover
+                                  //   all 32 banks
+__host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ == 32 ? 144 : LQ == 52 ? 208 : 272; }
+
 struct TrainPlan {
     int LQ;                    // layer-0 quarter length = MFMA steps of layer 0 (F <= 4*LQ)
     int XP;                    // X row pitch = 4*LQ + 4 floats
@@ -64,6 +73,10 @@ struct TrainPlan {
     int64_t NP;
     int64_t offW[5], offB[5];  // canonical parameter offsets per layer (index nl = last layer)
     int pk_w0, pk_wh, pk_wl, pack_floats;  // fragment-order buffer (floats)
+    int wave;                  // 1: the wave-local kernel runs this shape (fragment orders differ, see frag_pos)
+    int pk_wht, pk_wlt;        // wave-local kernel: W_l^T and W_last^T fragments for the backward products
+    int w_dp, w_df;            // 64 / (RP/4) and 64 % (RP/4): chunk walk of the row copy
+    int wave_lds_floats;
     int sl_hid, sl_out, sl_bias, slab_floats;  // slab (tile order) section starts, in floats
     int lds_x, lds_xt, lds_h, lds_ht, lds_z, lds_zt, lds_zo, lds_zot, lds_pix, lds_red, lds_floats;
 };
@@ -93,7 +106,19 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.pk_w0 = k; k += 4 * p.LQ * 64;
     p.pk_wh = k; k += (net.nl - 1) * 4 * 16 * 64;
     p.pk_wl = k; k += 16 * 64;
+    p.pk_wht = k; k += (net.nl - 1) * 4 * 16 * 64;
+    p.pk_wlt = k; k += 16 * 64;
     p.pack_floats = k;
+    {   // wave-local kernel: X [64][XP] + H, Z [nl][64][80] + Zo [64][16] + 4 doubles
+        const int xp = wave_xp(p.LQ);
+        p.wave_lds_floats = WB * xp + 2 * net.nl * WB * WHP + WB * WOP + 8;
+        p.wave = net.nl <= 2 && p.RP <= xp && 16 * p.NT0 <= xp && (size_t)p.wave_lds_floats * 4 <= 160 * 1024;
+        const char* force = getenv("LBDRN_TRAIN_KERNEL");     // "tile": the 8-wave tile kernel (A/B measurements)
+        if (force && force[0] == 't') p.wave = 0;
+        const int rp4 = p.RP / 4;
+        p.w_dp = 64 / rp4;
+        p.w_df = 64 % rp4;
+    }
     int s = 4 * p.NT0 * 256;
     p.sl_hid = s; s += (net.nl - 1) * 16 * 256;
     p.sl_out = s; s += 4 * 256;
