@@ -49,5 +49,9 @@ if __name__ == "__main__":
     if "--stamps" in sys.argv:  # diagnostic build with in-kernel s_memtime stamps (never benchmarked)
         print(build(force=True, extra=["-DLBDRN_TRAIN_STAMPS", "-DLBDRN_APPLY_STAMPS"],
                     out=os.path.join(os.path.dirname(HERE), "liblbdrn_hip_stamps.so")))
+    elif "--variant" in sys.argv:  # A/B build: python build.py --variant NAME -DFOO ... -> liblbdrn_hip_NAME.so
+        k = sys.argv.index("--variant")
+        print(build(force=True, extra=[a for a in sys.argv[k + 2:] if a.startswith("-D")],
+                    out=os.path.join(os.path.dirname(HERE), f"liblbdrn_hip_{sys.argv[k + 1]}.so")))
     else:
         print(build(force="--force" in sys.argv))

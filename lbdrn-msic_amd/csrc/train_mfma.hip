@@ -35,6 +35,7 @@
 // Training parity is a tolerance contract (1e-5 relative on the loss), not a bit
 // pattern: the summation order differs from the generic kernels and from torch.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.hpp"
@@ -64,6 +65,20 @@ constexpr int WOP = 16;           //   the weight-gradient operands are read one
                                   //   and lane quarters one row apart, so two quarters (one ds_read_b32 group) cover
                                   //   all 32 banks
 __host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ == 32 ? 144 : LQ == 52 ? 208 : 272; }
+constexpr int TBC_W = 64;
+constexpr int WPT = 68;   // [unit][64 samples] pitch of the transposed dz copies (16-byte rows, quarters 16 banks apart)
+
+__host__ __device__ constexpr int wave_region_floats(int NL)   // H1.. | dz^T | dz_out | loss partials
+{
+    return (NL - 1) * WB * WHP + NL * TBC_W * WPT + WB * WOP + 4 + 64;   // .. | 4 loss partials | [4 waves][16] output-bias partials
+}
+__host__ __device__ constexpr int wave_lds_total(int LQ, int NL)
+{
+    const int stage = LQ * 256;   // the layer-0 fragments: 4 tiles x LQ/4 blocks x 256 floats
+    const int region = wave_region_floats(NL);
+    return WB * wave_xp(LQ) + WB * WHP + (stage > region ? stage : region);
+}
+
 
 struct TrainPlan {
     int LQ;                    // layer-0 quarter length = MFMA steps of layer 0 (F <= 4*LQ)
@@ -111,7 +126,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.pack_floats = k;
     {   // wave-local kernel: X [64][XP] + H, Z [nl][64][80] + Zo [64][16] + 4 doubles
         const int xp = wave_xp(p.LQ);
-        p.wave_lds_floats = WB * xp + 2 * net.nl * WB * WHP + WB * WOP + 8;
+        p.wave_lds_floats = WB * xp + WB * WHP + std::max(p.LQ * 256, wave_region_floats(net.nl));
         p.wave = net.nl <= 2 && p.RP <= xp && 16 * p.NT0 <= xp && (size_t)p.wave_lds_floats * 4 <= 160 * 1024;
         const char* force = getenv("LBDRN_TRAIN_KERNEL");     // "tile": the 8-wave tile kernel (A/B measurements)
         if (force && force[0] == 't') p.wave = 0;
@@ -160,9 +175,10 @@ static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, 
     const size_t nwg = (size_t)(bs + TB - 1) / TB;
     L.off_slab = o; o += align_up(nwg * (size_t)p.slab_floats * sizeof(float), 256);
     L.off_loss = o; o += align_up(nwg * sizeof(double), 256);
-    L.stage_bytes = align_up(nwg * (size_t)TB * p.RP * sizeof(float), 256);  // one minibatch of rows, contiguous
+    // one minibatch of rows, contiguous, rounded up to whole workgroups of either kernel (32 / 64 rows)
+    L.stage_bytes = align_up(align_up((size_t)bs, WB) * p.RP * sizeof(float), 256);
     L.off_stage = o; o += 2 * L.stage_bytes;
-    L.off_map = o; o += align_up((size_t)p.slab_floats * 2 * sizeof(int), 256);  // slab element -> (param, fragment slot)
+    L.off_map = o; o += align_up((size_t)p.slab_floats * 4 * sizeof(int), 256);  // slab element -> (param, fragment slots)
     L.total = o;
     return L;
 }
@@ -277,31 +293,46 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// canonical parameter index -> position in the fragment-order buffer (or -1: not packed).
+// canonical parameter index -> positions in the fragment-order buffer (or -1: not packed): .x = the copy the forward
+// products read, .y = the transposed copy the wave-local kernel's backward products read.
 // Quarter-K order: MFMA step s of lane quarter q multiplies k = q*L + s.  Four consecutive steps of a
-// lane are adjacent ([step/4][lane][step%4]) so that the prefetch is one 16-byte load per four steps.
-__device__ __forceinline__ int frag_pos(int64_t idx, const TrainPlan& p, int F, int nl, int C)
+// lane are adjacent ([step/4][lane][step%4]) so that a fragment fetch is one 16-byte load per four steps.
+// Tile kernel (p.wave == 0): hidden and output layers walk k = 16q + s as well.
+// Wave-local kernel (p.wave == 1): the B operand of a hidden / output product is the previous layer's accumulator
+// as it stands in registers (lane quarter q, tile t, register r holds unit 16t + 4q + r), so step (t, r) multiplies
+// k = 16t + 4q + r; the backward products take W^T the same way (k = output unit of the layer).
+__device__ __forceinline__ int2 frag_pos(int64_t idx, const TrainPlan& p, int F, int nl, int C)
 {
     if (idx < p.offB[0]) {  // W0[n][k]
         int n = (int)(idx / F), k = (int)(idx - (int64_t)n * F);
         int q = k / p.LQ, s = k - q * p.LQ;
-        return p.pk_w0 + ((((n >> 4) * (p.LQ >> 2) + (s >> 2)) * 64 + q * 16 + (n & 15)) * 4 + (s & 3));
+        return make_int2(p.pk_w0 + ((((n >> 4) * (p.LQ >> 2) + (s >> 2)) * 64 + q * 16 + (n & 15)) * 4 + (s & 3)), -1);
     }
     for (int l = 1; l < nl; ++l) {
         if (idx >= p.offW[l] && idx < p.offB[l]) {  // W_l[n][k]
             int e = (int)(idx - p.offW[l]);
             int n = e >> 6, k = e & 63;
-            int sq = k & 15;
-            return p.pk_wh + (((((l - 1) * 4 + (n >> 4)) * 4 + (sq >> 2)) * 64 + (k >> 4) * 16 + (n & 15)) * 4 + (sq & 3));
+            if (!p.wave) {
+                int sq = k & 15;
+                return make_int2(p.pk_wh + (((((l - 1) * 4 + (n >> 4)) * 4 + (sq >> 2)) * 64 + (k >> 4) * 16 + (n & 15)) * 4 + (sq & 3)), -1);
+            }
+            const int fwd = p.pk_wh + (((((l - 1) * 4 + (n >> 4)) * 4 + (k >> 4)) * 64 + ((k >> 2) & 3) * 16 + (n & 15)) * 4 + (k & 3));
+            const int bwd = p.pk_wht + (((((l - 1) * 4 + (k >> 4)) * 4 + (n >> 4)) * 64 + ((n >> 2) & 3) * 16 + (k & 15)) * 4 + (n & 3));
+            return make_int2(fwd, bwd);
         }
     }
     if (idx >= p.offW[nl] && idx < p.offB[nl]) {  // W_last[c][k]
         int e = (int)(idx - p.offW[nl]);
         int c = e >> 6, k = e & 63;
-        int sq = k & 15;
-        return p.pk_wl + (((sq >> 2) * 64 + (k >> 4) * 16 + c) * 4 + (sq & 3));
+        if (!p.wave) {
+            int sq = k & 15;
+            return make_int2(p.pk_wl + (((sq >> 2) * 64 + (k >> 4) * 16 + c) * 4 + (sq & 3)), -1);
+        }
+        const int fwd = p.pk_wl + (((k >> 4) * 64 + ((k >> 2) & 3) * 16 + c) * 4 + (k & 3));
+        const int bwd = p.pk_wlt + (((k >> 4) * 64 + (c >> 2) * 16 + (k & 15)) * 4 + (c & 3));
+        return make_int2(fwd, bwd);
     }
-    return -1;
+    return make_int2(-1, -1);
 }
 
 // slab element (tile order) -> canonical parameter index (or -1: padding)
@@ -334,19 +365,21 @@ __global__ void __launch_bounds__(256)
 {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= p.NP) return;
-    int pos = frag_pos(idx, p, F, nl, C);
-    if (pos >= 0) packed[pos] = params[idx];
+    const int2 pos = frag_pos(idx, p, F, nl, C);
+    if (pos.x >= 0) packed[pos.x] = params[idx];
+    if (pos.y >= 0) packed[pos.y] = params[idx];
 }
 
-// map[e] = (canonical parameter index or -1, fragment-order slot or -1) of slab element e: the index
+// map[e] = (canonical parameter index or -1, fragment-order slots or -1) of slab element e: the index
 // arithmetic (integer divisions by F and LQ) is done once per epoch call, not in every reduce launch
 __global__ void __launch_bounds__(256)
-    k_build_map(TrainPlan p, int F, int nl, int C, int2* __restrict__ map)
+    k_build_map(TrainPlan p, int F, int nl, int C, int4* __restrict__ map)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.slab_floats) return;
     int64_t idx = e < p.sl_bias + nl * TBC + 16 ? slab_to_param(e, p, F, nl, C) : -1;
-    map[e] = make_int2((int)idx, idx >= 0 ? frag_pos(idx, p, F, nl, C) : -1);
+    const int2 pos = idx >= 0 ? frag_pos(idx, p, F, nl, C) : make_int2(-1, -1);
+    map[e] = make_int4((int)idx, pos.x, pos.y, 0);
 }
 
 // g[e] = sum over workgroups of slab[wg][e], in a fixed order (slices of nwg/RED_SLICES slabs summed in
@@ -355,7 +388,7 @@ __global__ void __launch_bounds__(256)
 // Block = RED_LANES float4 lanes (4*RED_LANES slab elements) x RED_SLICES workgroup slices; the final sum over
 // slices and the update are spread over 4*RED_LANES threads, one slab element each.
 __global__ void __launch_bounds__(256)
-    k_reduce_adam(const float* __restrict__ slabs, int nwg, int slab_floats, const int2* __restrict__ map,
+    k_reduce_adam(const float* __restrict__ slabs, int nwg, int slab_floats, const int4* __restrict__ map,
                   float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
                   float* __restrict__ packed, float step_size, float bc2_sqrt,
                   const double* __restrict__ loss_part, double loss_count, float* loss_out)
@@ -364,7 +397,7 @@ __global__ void __launch_bounds__(256)
     const int l16 = threadIdx.x % RED_LANES, slice = threadIdx.x / RED_LANES;
     const int base = blockIdx.x * (4 * RED_LANES);
     // the 32 updating threads fetch their parameter's state while the slab reads fly
-    int2 me = make_int2(-1, -1);
+    int4 me = make_int4(-1, -1, -1, 0);
     float pm = 0.f, pv = 0.f, pp = 0.f;
     if (threadIdx.x < 4 * RED_LANES) {
         me = map[base + threadIdx.x];
@@ -403,6 +436,7 @@ __global__ void __launch_bounds__(256)
         v[me.x] = vi;
         params[me.x] = pi;
         if (me.y >= 0) packed[me.y] = pi;
+        if (me.z >= 0) packed[me.z] = pi;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
         double s = 0.0;
@@ -824,6 +858,560 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 #endif
 }
 
+// ------------------------------------------------------------------ the wave-local step
+//
+// k_train_wave: 64 samples per workgroup, 4 waves (one per SIMD), each wave owns 16 samples from the row copy to
+// dL/dz of the first layer WITHOUT exchanging data with another wave: a layer's accumulators
+// (v_mfma_f32_16x16x4_f32: lane (i, q), tile t, register r = unit 16t+4q+r of sample i) are exactly the B operand of
+// the next product when that product walks k = 16t+4q+r (frag_pos, p.wave), forward and backward alike.  So the whole
+// forward + backpropagation is one dependency-free stream per wave -- four independent accumulator tiles per layer
+// (the 40-cycle dependent latency of the 32-cycle MFMA never shows), no LDS round trip between layers.
+//
+// What bounds a step on a CU is not the matrix pipe but the two narrow paths beside it: the vector-memory path
+// (64 B/clk per CU whether a line hits L1 or not) and the issue rate of LDS instructions of a single wave.  Hence:
+//  * the layer-0 weights (53 of the 93 KB a wave multiplies by) are fetched ONCE per workgroup, straight into LDS
+//    (global_load_lds, each wave a quarter), over the regions that hold H1 / dz^T later, and read from there as
+//    fragments (ds_read_b128, 256 B/clk); the small matrices of the other products come L2 -> VGPR while layer 0 runs;
+//  * weight gradients sum over the 64 samples of the workgroup: dz is parked TRANSPOSED ([unit][sample], samples
+//    permuted so that lane quarter q finds its 16 samples in one 64-byte piece), so the A operands of a whole layer
+//    (4 tiles x 16 steps) are 16 ds_read_b128; each wave then takes every fourth 16-column strip of the inputs and
+//    multiplies all four unit tiles against it (64 MFMAs per 16 one-float reads of the row-major inputs).
+// Three workgroup barriers: rows + layer-0 weights in LDS; layer 0 done (its weights' space is reused); dz complete.
+// A minibatch of 8192 rows is 128 workgroups: the gradient slab exchange is half the tile kernel's, and two fits in
+// flight on one GPU run side by side on disjoint halves of the chip instead of taking turns.
+// fast sigmoid for the training step (a tolerance contract, 1e-5 on the loss): v_exp + v_rcp, ~1e-7 relative
+__device__ __forceinline__ float train_sigmoid(float z)
+{
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * __builtin_fabsf(z));   // e^-|z|
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return z >= 0.0f ? r : e * r;
+}
+
+// sum over the 64 lanes, same order every time, no LDS: rows of 16 by DPP shifts, then the four row totals
+// sum over each row of 16 lanes (DPP shifts, zero fill): lane 15 of a row holds the row's total
+__device__ __forceinline__ float row_sum16(float x)
+{
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x111, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x112, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x114, 0xf, 0xf, true));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x118, 0xf, 0xf, true));
+    return x;
+}
+
+// sum over the 64 lanes, same order every time, no LDS: the four row totals, then (0 + 1) + (2 + 3)
+__device__ __forceinline__ float wave_sum(float x)
+{
+    const int xi = __float_as_int(row_sum16(x));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(xi, 15)), b = __int_as_float(__builtin_amdgcn_readlane(xi, 31));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(xi, 47)), d = __int_as_float(__builtin_amdgcn_readlane(xi, 63));
+    return (a + b) + (c + d);
+}
+
+template <int LQ, int NL>
+__global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const TrainPlan& p = A.p;
+    constexpr int XP = wave_xp(LQ), HP = WHP, OP = WOP, PT = WPT, G0 = LQ / 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler should know it
+    const int i = lane & 15, q = lane >> 4;
+    const int C = A.net.C, F = A.net.F;
+    float* Xs = lds;                        // [64][XP]  features | labels, row-major
+    float* H0 = Xs + WB * XP;               // [64][HP]  activations of layer 0
+    float* R = H0 + WB * HP;                // region shared in time: layer-0 fragments, then
+    float* Hx = R;                          //   [NL-1][64][HP] activations of layers 1..
+    float* ZT = Hx + (NL - 1) * WB * HP;    //   [NL][64 units][PT] dL/dz transposed, column = 16 (s & 3) + (s >> 2)
+    float* Zo = ZT + NL * TBC * PT;         //   [64][OP]  dL/dz of the output layer
+    float* red = Zo + WB * OP;              //   [4] loss partials, then [4 waves][16 slots] output-bias partials
+    const float* W0s = R;                   // [4 tiles][G0 blocks][64 lanes][4]
+    auto Hl = [&](int l) -> float* { return l == 0 ? H0 : Hx + (size_t)(l - 1) * WB * HP; };
+    const int wg = blockIdx.x, first = wg * WB;
+    const int nvalid = min(WB, A.batch_n - first);
+    const int srow = 16 * w + i;            // this lane's sample (column of every forward / backward tile)
+    float* slab = A.slabs + (size_t)wg * p.slab_floats;
+    const WtBuf slabw(slab, (size_t)p.slab_floats * 4);
+#ifdef LBDRN_TRAIN_STAMPS
+    unsigned long long stamp[16] = {};
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[14])::"memory");
+#endif
+    STAMP(0);
+
+    // which rows: lane j (mod 16) fetches the pixel index of row j of this wave -- of this minibatch when it has to
+    // gather for itself, of the next one for the staging -- and the row copies below pick theirs up by shuffle
+    // (a load per chunk would chain every row request behind an index load: loads retire in order)
+    const bool do_next = A.stage_out != nullptr && first < A.next_n;
+    // (rows past the end repeat the last row: finite values; the raw index is clamped where it is used, so that
+    //  nothing here waits for the load)
+    auto clamp_pix = [&](int64_t pix) -> int { return (int)(pix < 0 ? 0 : (pix >= A.npix ? A.npix - 1 : pix)); };
+    const int64_t raw_mine = A.stage_in == nullptr ? A.perm[min(first + 16 * w + i, A.batch_n - 1)] : 0;
+    const int64_t raw_next = do_next ? A.perm_next[min(first + 16 * w + i, A.next_n - 1)] : raw_mine;
+    // biases: tiny, and the first MFMA of every layer starts from them -- ahead of every other request
+    f32x4 bias[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float4 b4 = *reinterpret_cast<const float4*>(A.params + p.offB[l] + 16 * t + 4 * q);
+            bias[l][t][0] = b4.x; bias[l][t][1] = b4.y; bias[l][t][2] = b4.z; bias[l][t][3] = b4.w;
+        }
+    f32x4 bias_last;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? A.params[p.offB[NL] + 4 * q + r] : 0.0f;
+
+    // ---- rows: the wave copies its own 16 rows (16 * RP/4 chunks of 16 B, chunk c = lane + 64 u).  Staged by the
+    //      previous launch they are one contiguous 13 KB piece; the first step of an epoch gathers for itself.
+    //      When the LDS row pitch equals the matrix row pitch (the headline shape: 208 floats) the 16 rows are one
+    //      contiguous piece in LDS too and go there by LDS-DMA like the weights: no registers, no ds_write, and every
+    //      request of the prologue in flight at once (a ds_write behind an LDS-DMA waits for vmcnt(0)).
+    constexpr int NLD = (16 * (XP / 4) + 63) / 64;
+    const int rp4 = p.RP >> 2, nchunk = 16 * rp4;
+    const int row0 = lane / rp4, col0 = lane - row0 * rp4;
+#define LBDRN_LDS_DMA(gptr, lptr) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+    const bool dma_rows = p.RP == XP;
+    if (dma_rows) {
+        float* dst = Xs + 16 * w * XP;
+        if (A.stage_in != nullptr) {
+            const float* src = A.stage_in + (size_t)(first + 16 * w) * p.RP + lane * 4;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u)
+                if (lane + 64 * u < nchunk) LBDRN_LDS_DMA(src + u * 256, dst + u * 256);
+        } else {
+            const int pix_mine = clamp_pix(raw_mine);
+            const float* srcs[NLD];
+            int row = row0, col = col0;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                srcs[u] = A.rows + (size_t)__shfl(pix_mine, min(row, 15)) * p.RP + 4 * col;
+                row += p.w_dp; col += p.w_df;
+                if (col >= rp4) { col -= rp4; row += 1; }
+            }
+#pragma unroll
+            for (int u = 0; u < NLD; ++u)
+                if (lane + 64 * u < nchunk) LBDRN_LDS_DMA(srcs[u], dst + u * 256);
+        }
+    }
+    // ---- layer-0 fragments -> LDS, this wave's quarter (tile w: G0 blocks of 1 KB, contiguous in the packed copy)
+    {
+        const float* src = A.packed + p.pk_w0 + (size_t)w * G0 * 256 + lane * 4;
+        float* dst = R + w * G0 * 256;
+#pragma unroll
+        for (int g = 0; g < G0; ++g) LBDRN_LDS_DMA(src + g * 256, dst + g * 256);
+    }
+#undef LBDRN_LDS_DMA
+    // (chunks past the end of the 16 rows -- the last lanes of the last pass -- redo the last chunk: same address,
+    //  same data, and no lane-dependent branch for the compiler to sink the loads into)
+#define LBDRN_ROWS_TO_LDS(v)                                                                                          \
+    {                                                                                                                 \
+        int row = row0, col = col0;                                                                                   \
+        _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                             \
+            const bool in = lane + 64 * u < nchunk;                                                                   \
+            *reinterpret_cast<float4*>(Xs + (16 * w + (in ? row : 15)) * XP + 4 * (in ? col : rp4 - 1)) = v[u];       \
+            row += p.w_dp; col += p.w_df;                                                                             \
+            if (col >= rp4) { col -= rp4; row += 1; }                                                                 \
+        }                                                                                                             \
+    }
+    if (!dma_rows) {
+        if (A.stage_in != nullptr) {
+            const float4* src = reinterpret_cast<const float4*>(A.stage_in + (size_t)(first + 16 * w) * p.RP);
+            float4 v[NLD];
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) v[u] = src[min(lane + 64 * u, nchunk - 1)];
+            LBDRN_ROWS_TO_LDS(v)
+        } else {
+            float4 v[NLD];
+            const int pix_mine = clamp_pix(raw_mine);
+            int row = row0, col = col0;
+#pragma unroll
+            for (int u = 0; u < NLD; ++u) {
+                const bool in = lane + 64 * u < nchunk;
+                const int pix = __shfl(pix_mine, in ? row : 15);
+                v[u] = *reinterpret_cast<const float4*>(A.rows + (size_t)pix * p.RP + 4 * (in ? col : rp4 - 1));
+                row += p.w_dp; col += p.w_df;
+                if (col >= rp4) { col -= rp4; row += 1; }
+            }
+            LBDRN_ROWS_TO_LDS(v)
+        }
+        const int padc = XP / 4 - rp4;   // columns RP..XP-1: read by layer-0 steps / dW0 strips past the row, must be finite
+        for (int c = lane; c < 16 * padc; c += 64) {
+            const int r = c / padc, cc = c - r * padc;
+            *reinterpret_cast<float4*>(Xs + (16 * w + r) * XP + 4 * (rp4 + cc)) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#undef LBDRN_ROWS_TO_LDS
+    // where the next minibatch's rows are (shuffles now: the gather requests ride inside layer 0)
+    int nx_pix[NLD], nx_col[NLD];
+    {
+        const int pix_next = clamp_pix(raw_next);
+        int row = row0, col = col0;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const bool in = lane + 64 * u < nchunk;
+            nx_pix[u] = __shfl(pix_next, in ? row : 15);
+            nx_col[u] = in ? col : rp4 - 1;
+            row += p.w_dp; col += p.w_df;
+            if (col >= rp4) { col -= rp4; row += 1; }
+        }
+    }
+    STAMP(1);
+    __syncthreads();   // rows and layer-0 fragments of all four waves are in LDS (drains the LDS-DMA: vmcnt(0))
+    STAMP(2);
+
+    // ---- every other request of the step rides inside layer 0, a few per group of 16 MFMAs, where the vector-memory
+    //      path is otherwise idle (a burst of them stalls the wave: the path takes 64 B/clk per CU): the small matrices
+    //      of the following products (L2 -> VGPR, fragment order), then the transposed ones of the backward products,
+    //      then -- last, because loads retire in order and these are random 832-byte rows from HBM -- the next
+    //      minibatch's rows, parked in the staging buffer during the weight-gradient phase.
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.packed), (short)0,
+                                                                         p.pack_floats * 4, 0x00020000);
+    const int lane16 = lane * 16;
+    auto ldw = [&](int float_base, int block) -> float4 {
+        const v4i32 x = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, float_base * 4 + block * 1024, 0);
+        return make_float4(__int_as_float(x[0]), __int_as_float(x[1]), __int_as_float(x[2]), __int_as_float(x[3]));
+    };
+    float4 wh[NL > 1 ? NL - 1 : 1][4][4];    // W_l fragments [out tile][k tile]
+    float4 wl[4];                            // W_last fragments [k tile]
+    float4 wlt[4];                           // W_last^T [hidden tile]
+    float4 wht[NL > 1 ? NL - 1 : 1][4][4];   // W_l^T [in tile][out tile]
+    float4 vnext[NLD];
+    constexpr int NH = (NL - 1) * 16, NREQ = 2 * NH + 8 + NLD, PERG = (NREQ + G0 - 1) / G0;
+
+    // ---- layer 0: z^T[64 units][16 samples] = b0 + W0 X^T; lane quarter q walks features q*LQ .. q*LQ+LQ-1.
+    //      Operands of group g+1 (4 fragment blocks + 4 features, LDS) are requested among the 16 MFMAs of group g:
+    //      one wave per SIMD has nobody to hide an instruction burst behind, so reads and requests are dealt out
+    //      between the MFMAs (sched_group_barrier) instead of left where the scheduler would sink them.
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = bias[0][t];
+    {
+        const float* wbase = W0s + lane * 4;
+        const float* xbase = Xs + srow * XP + q * LQ;
+        float4 aq[2][4], bq[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) aq[0][t] = *reinterpret_cast<const float4*>(wbase + (t * G0) * 256);
+        bq[0] = *reinterpret_cast<const float4*>(xbase);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < G0; ++g) {
+            if (g + 1 < G0) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) aq[(g + 1) & 1][t] = *reinterpret_cast<const float4*>(wbase + (t * G0 + g + 1) * 256);
+                bq[(g + 1) & 1] = *reinterpret_cast<const float4*>(xbase + 4 * (g + 1));
+            }
+#pragma unroll
+            for (int j = g * PERG; j < (g + 1) * PERG; ++j) {
+                if (j < NH) wh[j / 16][(j >> 2) & 3][j & 3] = ldw(p.pk_wh, j);
+                else if (j < NH + 4) wl[j - NH] = ldw(p.pk_wl, j - NH);
+                else if (j < NH + 8) wlt[j - NH - 4] = ldw(p.pk_wlt, j - NH - 4);
+                else if (j < 2 * NH + 8) {
+                    const int k = j - NH - 8;   // (l-1)*16 + ti*4 + to
+                    wht[k / 16][(k >> 2) & 3][k & 3] = ldw(p.pk_wht, k);
+                } else if (j < NREQ) {
+                    const int u = j - 2 * NH - 8;
+                    vnext[u] = *reinterpret_cast<const float4*>(A.rows + (size_t)nx_pix[u] * p.RP + 4 * nx_col[u]);
+                }
+            }
+            const float bx[4] = {bq[g & 1].x, bq[g & 1].y, bq[g & 1].z, bq[g & 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 x = aq[g & 1][t];
+                    acc[t] = MFMA16(e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w, bx[e], acc[t]);
+                }
+            // the dealt order of this group: MFMA, then a read or a request after every MFMA while there are any
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP(3);
+    __syncthreads();   // every wave is done with the layer-0 fragments: their space now takes H1.. / dz^T / dz_out
+    STAMP(4);
+
+    float h[4][4];        // the current layer's activations, accumulator layout
+    f32x4 cs[NL][4];      // cos(30 z) of every hidden layer, for the backward pass
+    auto activate = [&](int l) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sn, co;
+                canon_sincos(30.0f * acc[t][r], sn, co);
+                h[t][r] = sn;
+                cs[l][t][r] = co;
+            }
+            *reinterpret_cast<float4*>(Hl(l) + srow * HP + 16 * t + 4 * q) = make_float4(h[t][0], h[t][1], h[t][2], h[t][3]);
+        }
+    };
+    activate(0);
+    STAMP(5);
+
+    // ---- hidden layers: B = the activations where they stand (step (tk, r) multiplies unit 16 tk + 4 q + r)
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = bias[l][t];
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int to = 0; to < 4; ++to) {
+                    const float4 x = wh[l - 1][to][tk];
+                    const float a = r == 0 ? x.x : r == 1 ? x.y : r == 2 ? x.z : x.w;
+                    acc[to] = MFMA16(a, h[tk][r], acc[to]);
+                }
+        }
+        activate(l);
+    }
+    STAMP(6);
+
+    // ---- output layer (two accumulators share the 16-step chain) + loss + d(loss)/dz_out
+    float dzo[4];
+    {
+        f32x4 oe = bias_last, oo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tk = 0; tk < 4; ++tk) {
+            const float4 x = wl[tk];
+            oe = MFMA16(x.x, h[tk][0], oe);
+            oo = MFMA16(x.y, h[tk][1], oo);
+            oe = MFMA16(x.z, h[tk][2], oe);
+            oo = MFMA16(x.w, h[tk][3], oo);
+        }
+        const bool live = srow < nvalid;
+        const float* labrow = Xs + srow * XP + F + 4 * q;   // labels ride behind the features (F need not be a multiple of 4)
+        float lsum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = live && (4 * q + r) < C;
+            const float y = train_sigmoid(oe[r] + oo[r]);
+            const float d = y - ((4 * q + r) < C ? labrow[r] : 0.0f);
+            lsum += ok ? d * d : 0.0f;                                      // ref LBDRNloss.py:9
+            dzo[r] = ok ? ((2.0f * d) * A.inv) * (y * (1.0f - y)) : 0.0f;    // mse + sigmoid backward
+        }
+        *reinterpret_cast<float4*>(Zo + srow * OP + 4 * q) = make_float4(dzo[0], dzo[1], dzo[2], dzo[3]);
+        lsum = wave_sum(lsum);   // 64 terms in float32 (1e-7 relative), the workgroups' partials are summed in double
+        if (lane == 0) red[w] = lsum;
+        // output-bias gradient of this wave's 16 samples: row sums by DPP, lane 15 of quarter q holds channels 4q..4q+3
+        float bs[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[r] = row_sum16(dzo[r]);
+        if (i == 15) *reinterpret_cast<float4*>(red + 4 + 16 * w + 4 * q) = make_float4(bs[0], bs[1], bs[2], bs[3]);
+    }
+    STAMP(7);
+
+    // ---- backward: dh = W^T dz, dz = (dh * cos(30 z)) * 30, layer by layer, still wave-local.  dz is parked
+    //      transposed: unit row, column 16 (s & 3) + (s >> 2) of sample s -- the weight-gradient products then find
+    //      the 16 samples of lane quarter q (samples 4 j + q) in one 64-byte piece
+    const int zcol = 16 * (i & 3) + 4 * w + (i >> 2);
+    float dz[4][4];
+    auto backprop = [&](int l) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dz[t][r] = (acc[t][r] * cs[l][t][r]) * 30.0f;
+                ZT[(size_t)l * TBC * PT + (16 * t + 4 * q + r) * PT + zcol] = dz[t][r];
+            }
+    };
+    {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = zero;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float4 x = wlt[t];
+                const float a = s == 0 ? x.x : s == 1 ? x.y : s == 2 ? x.z : x.w;
+                acc[t] = MFMA16(a, dzo[s], acc[t]);
+            }
+        backprop(NL - 1);
+    }
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = zero;
+#pragma unroll
+        for (int to = 0; to < 4; ++to)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) {
+                    const float4 x = wht[l - 1][ti][to];
+                    const float a = r == 0 ? x.x : r == 1 ? x.y : r == 2 ? x.z : x.w;
+                    acc[ti] = MFMA16(a, dz[to][r], acc[ti]);
+                }
+        backprop(l - 1);
+    }
+    STAMP(8);
+    __syncthreads();
+    if (tid == 0) A.loss_part[wg] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    STAMP(9);
+
+    // ---- weight gradients: K = the 64 samples (16 steps; lane quarter q, step j = sample 4 j + q).
+    //      dW[unit tile t][input strip nt]: A = dz^T rows of tile t (16 contiguous floats per lane), B = the inputs
+    //      row-major, one float per lane and step.  Wave w takes the strips nt = w, w+4, .. of the first layer against
+    //      all four unit tiles (64 MFMAs on four independent accumulators per 16 reads); the strips left over when
+    //      the strip count is not a multiple of 4 go one tile to each wave; strip w of the hidden layers; tile w of
+    //      the output layer.  Every finished tile leaves as one 1 KB store in the slab's tile order.
+    auto ldrow = [&](const float* row, float (&dst)[16]) {   // 16 contiguous floats of a 16-byte aligned row piece
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 x = *reinterpret_cast<const float4*>(row + 4 * g);
+            dst[4 * g] = x.x; dst[4 * g + 1] = x.y; dst[4 * g + 2] = x.z; dst[4 * g + 3] = x.w;
+        }
+    };
+    auto ldcol = [&](const float* base, int pitch, float (&dst)[16]) {   // column i of 16 rows 4 j + q
+#pragma unroll
+        for (int s = 0; s < 16; ++s) dst[s] = base[(4 * s + q) * pitch + i];
+    };
+    auto put = [&](int off, const f32x4& g, bool early) {
+        if (early) slabw.store(off + lane * 4, g[0], g[1], g[2], g[3]);
+        else slabw.store_plain(off + lane * 4, g[0], g[1], g[2], g[3]);
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int NT0 = p.NT0, NF = NT0 & ~3, rem = NT0 - NF;
+    float az[4][16], b[16], bn[16];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ldrow(ZT + (16 * t + i) * PT + 16 * q, az[t]);
+    ldcol(Xs + 16 * min(w, NT0 - 1), XP, b);
+    __builtin_amdgcn_sched_barrier(0);
+    auto strip = [&](int nt, int nreads) {   // 64 MFMAs of strip nt (operands in az, b), four 1 KB tile stores; the
+        f32x4 g[4] = {zero4, zero4, zero4, zero4};   // nreads LDS reads requested just before are dealt out between them
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = MFMA16(az[t][s], b[s], g[t]);
+        if (nreads <= 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 52; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) put((t * NT0 + nt) * 256, g[t], true);
+    };
+    int nt = w;
+    for (; nt + 4 < NF; nt += 4) {   // operands of the strip after this one arrive under its MFMAs
+        ldcol(Xs + 16 * (nt + 4), XP, bn);
+        strip(nt, 16);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) b[s] = bn[s];
+    }
+    // left-over strips of the first layer (tile w of each) and tile w of the output layer: operands requested under
+    // the last full strip.  dW_last[channel slot][hidden 16w..] = sum_s dzo[s][slot] * h_last[s][16w + col]
+    float azw[16], ao[16], bo[16], br[16];
+    ldrow(ZT + (16 * w + i) * PT + 16 * q, azw);
+    ldcol(Zo, OP, ao);
+    ldcol(Hl(NL - 1) + 16 * w, HP, bo);
+    ldcol(Xs + 16 * min(NF, NT0 - 1), XP, br);
+    if (nt < NF) strip(nt, 52);
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(10);
+    if (do_next) {   // park the next minibatch's rows, contiguous, written through
+        float* dst = A.stage_out + (size_t)(first + 16 * w) * p.RP;   // (w is scalar: a uniform descriptor)
+        const WtBuf stw(dst, (size_t)16 * p.RP * 4);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int c = min(lane + 64 * u, nchunk - 1);   // (past the end: the last chunk again, same data)
+#ifdef LBDRN_STAGE_PLAIN
+            stw.store_plain(4 * c, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
+#else
+            stw.store(4 * c, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
+#endif
+        }
+    }
+    // hidden layers' operands (strip w of H_{l-1}, the four unit tiles of dz_l): requested under the tail's MFMAs
+    float a1[NL > 1 ? NL - 1 : 1][4][16], bh[NL > 1 ? NL - 1 : 1][16];
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ldrow(ZT + (size_t)l * TBC * PT + (16 * t + i) * PT + 16 * q, a1[l - 1][t]);
+        ldcol(Hl(l - 1) + 16 * w, HP, bh[l - 1]);
+    }
+    {
+        f32x4 go = zero4, g0 = zero4;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            go = MFMA16(ao[s], bo[s], go);
+            g0 = MFMA16(azw[s], br[s], g0);
+        }
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {   // the hidden layers' 32 operand reads, one after every MFMA of the tail
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        put(p.sl_out + w * 256, go, false);
+        if (rem >= 1) put((w * NT0 + NF) * 256, g0, false);
+    }
+    for (int k = 1; k < rem; ++k) {   // (strip counts 4n+2, 4n+3: rare shapes, one plain chain per extra strip)
+        ldcol(Xs + 16 * (NF + k), XP, br);
+        f32x4 g1 = zero4;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) g1 = MFMA16(azw[s], br[s], g1);
+        put((w * NT0 + NF + k) * 256, g1, false);
+    }
+#pragma unroll
+    for (int l = 1; l < NL; ++l) {
+        f32x4 g[4] = {zero4, zero4, zero4, zero4};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) g[t] = MFMA16(a1[l - 1][t][s], bh[l - 1][s], g[t]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) put(p.sl_hid + ((l - 1) * 16 + t * 4 + w) * 256, g[t], false);
+    }
+    STAMP(11);
+    // bias gradients: sums over the 64 samples.  Hidden units: a row of dz^T, two threads per unit (32 columns
+    // each, partner = lane ^ 1, summed low half first); output slots: a column of dz_out on the last wave.
+    if (tid < NL * TBC * 2) {
+        const int u = tid >> 1, half = tid & 1;
+        const float* row = ZT + (size_t)u * PT + 32 * half;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 x = *reinterpret_cast<const float4*>(row + 4 * g);
+            s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w;
+        }
+        const float mine = (s0 + s1) + (s2 + s3);
+        const float other = __shfl_xor(mine, 1);
+        if (half == 0) slab[p.sl_bias + u] = mine + other;
+    }
+    if (w == 3 && lane < 16)   // output slots: the four waves' partials (loss phase), in wave order
+        slab[p.sl_bias + NL * TBC + lane] = (red[4 + lane] + red[20 + lane]) + (red[36 + lane] + red[52 + lane]);
+    STAMP(12);
+#ifdef LBDRN_TRAIN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(13);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[15])::"memory");
+    if (lane == 0 && A.stamps)
+        for (int k = 0; k < 16; ++k) A.stamps[((size_t)wg * 4 + w) * 16 + k] = stamp[k];
+#endif
+}
+
 // ------------------------------------------------------------------ host driver
 
 template <int LQ, int NL>
@@ -850,8 +1438,48 @@ static int dispatch_nl(const TrainArgs& A, int nwg, hipStream_t s)
     return launch_train<LQ, 3>(A, nwg, s);
 }
 
+template <int LQ, int NL>
+static int launch_wave(const TrainArgs& A, int nwg, hipStream_t s)
+{
+    auto kern = k_train_wave<LQ, NL>;
+    kern<<<nwg, WAVE_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
+    LBDRN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int LQ, int NL>
+static int configure_wave(const TrainPlan& p)
+{
+    LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_wave<LQ, NL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, p.wave_lds_floats * 4));
+    return 0;
+}
+
+// once per epoch call (the attribute belongs to the current device's copy of the kernel)
+static int configure_wave_kernel(const TrainPlan& p, int nl)
+{
+    switch (p.LQ) {
+        case 16: return nl == 1 ? configure_wave<16, 1>(p) : configure_wave<16, 2>(p);
+        case 32: return nl == 1 ? configure_wave<32, 1>(p) : configure_wave<32, 2>(p);
+        case 52: return nl == 1 ? configure_wave<52, 1>(p) : configure_wave<52, 2>(p);
+        default: return nl == 1 ? configure_wave<64, 1>(p) : configure_wave<64, 2>(p);
+    }
+}
+
+static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
+{
+    const bool one = A.net.nl == 1;
+    switch (A.p.LQ) {
+        case 16: return one ? launch_wave<16, 1>(A, nwg, s) : launch_wave<16, 2>(A, nwg, s);
+        case 32: return one ? launch_wave<32, 1>(A, nwg, s) : launch_wave<32, 2>(A, nwg, s);
+        case 52: return one ? launch_wave<52, 1>(A, nwg, s) : launch_wave<52, 2>(A, nwg, s);
+        default: return one ? launch_wave<64, 1>(A, nwg, s) : launch_wave<64, 2>(A, nwg, s);
+    }
+}
+
 static int dispatch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
+    if (A.p.wave) return dispatch_wave(A, nwg, s);
     switch (A.p.LQ) {
         case 16: return dispatch_nl<16>(A, nwg, s);
         case 32: return dispatch_nl<32>(A, nwg, s);
@@ -922,20 +1550,23 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
     LBDRN_LAUNCH_CHECK();
     A.net = net; A.rows = rows; A.npix = (int64_t)g.H * g.W; A.params = params; A.packed = packed;
     A.slabs = slabs; A.loss_part = loss_part;
-    int2* map = (int2*)((char*)ws + L.off_map);
+    int4* map = (int4*)((char*)ws + L.off_map);
     k_build_map<<<(unsigned)((A.p.slab_floats + 255) / 256), 256, 0, s>>>(A.p, net.F, net.nl, net.C, map);
     LBDRN_LAUNCH_CHECK();
     float* stage[2] = {(float*)((char*)ws + L.off_stage), (float*)((char*)ws + L.off_stage + L.stage_bytes)};
     A.stamps = nullptr;
 #ifdef LBDRN_TRAIN_STAMPS
     const int max_wg = (bs + TB - 1) / TB;
-    LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 16 * sizeof(unsigned long long)));
+    LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 4 * 16 * sizeof(unsigned long long)));
 #endif
+    if (A.p.wave)
+        if (int rc = configure_wave_kernel(A.p, net.nl)) return rc;
+    const int rows_per_wg = A.p.wave ? WB : TB;
     int64_t step = step0;
     int si = 0;
     for (int64_t first = 0; first < n; first += bs, ++si) {
         const int B = (int)std::min<int64_t>(bs, n - first);
-        const int nwg = (B + TB - 1) / TB;
+        const int nwg = (B + rows_per_wg - 1) / rows_per_wg;
         A.perm = perm + first;
         A.batch_n = B;
         A.inv = 1.0f / ((float)B * (float)net.C);
@@ -957,7 +1588,28 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
         LBDRN_LAUNCH_CHECK();
     }
 #ifdef LBDRN_TRAIN_STAMPS
-    {   // diagnostic: mean cycles per phase over the workgroups of the last step
+    if (A.p.wave) {   // diagnostic: mean cycles per phase over the waves of the last step
+        LBDRN_HIP_TRY(hipStreamSynchronize(s));
+        const int nw = ((int)std::min<int64_t>(bs, n) + WB - 1) / WB * 4;
+        std::vector<unsigned long long> h((size_t)nw * 16);
+        LBDRN_HIP_TRY(hipMemcpy(h.data(), A.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(A.stamps);
+        double d[14] = {}, clk = 0, span = 0;
+        unsigned long long t0min = ~0ull, t1max = 0;
+        for (int k = 0; k < nw; ++k) {
+            for (int j = 1; j <= 13; ++j) d[j] += (double)(h[k * 16 + j] - h[k * 16 + j - 1]);
+            clk += (double)(h[k * 16 + 13] - h[k * 16 + 0]) / (double)(h[k * 16 + 15] - h[k * 16 + 14]) * 100.0;
+            span += (double)(h[k * 16 + 13] - h[k * 16 + 0]);
+            t0min = std::min(t0min, h[k * 16 + 14]);
+            t1max = std::max(t1max, h[k * 16 + 15]);
+        }
+        fprintf(stderr, "[lbdrn stamps, wave kernel] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
+                        "mean cycles: W0 DMA + rows->LDS %.0f | barrier 1 %.0f | small-matrix requests + layer0 %.0f | barrier 2 + W^T/next-row requests %.0f | "
+                        "act0 %.0f | hidden+act %.0f | out+loss %.0f | backward %.0f | barrier 3 %.0f | dW0 strips %.0f | park rows, dW tail+hidden %.0f | "
+                        "bias sums %.0f | drain %.0f\n",
+                clk / nw, span / nw, (double)(t1max - t0min) / 100.0, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw, d[5] / nw, d[6] / nw,
+                d[7] / nw, d[8] / nw, d[9] / nw, d[10] / nw, d[11] / nw, d[12] / nw, d[13] / nw);
+    } else {   // diagnostic: mean cycles per phase over the workgroups of the last step
         LBDRN_HIP_TRY(hipStreamSynchronize(s));
         std::vector<unsigned long long> h((size_t)max_wg * 16);
         LBDRN_HIP_TRY(hipMemcpy(h.data(), A.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));

@@ -1,6 +1,7 @@
 """A/B aid: wall time per tile of codec.fit_many over 6 tiles with 1 and 2 fits in flight, for the train
 kernel named by LBDRN_TRAIN_KERNEL (unset = k_train_mfma, 'lean' = k_train_lean)."""
 import os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # like bench.py: one hardware queue per fit in flight
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lbdrn-msic_amd"))
 import torch
