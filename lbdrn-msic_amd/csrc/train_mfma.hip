@@ -937,15 +937,12 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #endif
     STAMP(0);
 
-    // which rows: lane j (mod 16) fetches the pixel index of row j of this wave -- of this minibatch when it has to
-    // gather for itself, of the next one for the staging -- and the row copies below pick theirs up by shuffle
-    // (a load per chunk would chain every row request behind an index load: loads retire in order)
-    const bool do_next = A.stage_out != nullptr && first < A.next_n;
+    // which rows: lane j (mod 16) fetches the pixel index of row j of this wave; the row copy below picks its
+    // rows up by shuffle (a load per chunk would chain every row request behind an index load: loads retire in order)
     // (rows past the end repeat the last row: finite values; the raw index is clamped where it is used, so that
     //  nothing here waits for the load)
     auto clamp_pix = [&](int64_t pix) -> int { return (int)(pix < 0 ? 0 : (pix >= A.npix ? A.npix - 1 : pix)); };
     const int64_t raw_mine = A.stage_in == nullptr ? A.perm[min(first + 16 * w + i, A.batch_n - 1)] : 0;
-    const int64_t raw_next = do_next ? A.perm_next[min(first + 16 * w + i, A.next_n - 1)] : raw_mine;
     // biases: tiny, and the first MFMA of every layer starts from them -- ahead of every other request
     f32x4 bias[NL][4];
 #pragma unroll
@@ -959,9 +956,10 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? A.params[p.offB[NL] + 4 * q + r] : 0.0f;
 
-    // ---- rows: the wave copies its own 16 rows (16 * RP/4 chunks of 16 B, chunk c = lane + 64 u).  Staged by the
-    //      previous launch they are one contiguous 13 KB piece; the first step of an epoch gathers for itself.
-    //      When the LDS row pitch equals the matrix row pitch (the headline shape: 208 floats) the 16 rows are one
+    // ---- rows: the wave copies its own 16 rows (16 * RP/4 chunks of 16 B, chunk c = lane + 64 u), gathered from the
+    //      [N][RP] row matrix by pixel index (a staging buffer filled one launch ahead, as the tile kernel keeps, buys
+    //      nothing here: with every request of the prologue in flight at once the gather lands as fast as a contiguous
+    //      read -- measured -- and it costs a gather, a store and a read of 6.8 MB per step).  When the LDS row pitch equals the matrix row pitch (the headline shape: 208 floats) the 16 rows are one
     //      contiguous piece in LDS too and go there by LDS-DMA like the weights: no registers, no ds_write, and every
     //      request of the prologue in flight at once (a ds_write behind an LDS-DMA waits for vmcnt(0)).
     constexpr int NLD = (16 * (XP / 4) + 63) / 64;
@@ -1041,29 +1039,13 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
         }
     }
 #undef LBDRN_ROWS_TO_LDS
-    // where the next minibatch's rows are (shuffles now: the gather requests ride inside layer 0)
-    int nx_pix[NLD], nx_col[NLD];
-    {
-        const int pix_next = clamp_pix(raw_next);
-        int row = row0, col = col0;
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const bool in = lane + 64 * u < nchunk;
-            nx_pix[u] = __shfl(pix_next, in ? row : 15);
-            nx_col[u] = in ? col : rp4 - 1;
-            row += p.w_dp; col += p.w_df;
-            if (col >= rp4) { col -= rp4; row += 1; }
-        }
-    }
     STAMP(1);
     __syncthreads();   // rows and layer-0 fragments of all four waves are in LDS (drains the LDS-DMA: vmcnt(0))
     STAMP(2);
 
     // ---- every other request of the step rides inside layer 0, a few per group of 16 MFMAs, where the vector-memory
     //      path is otherwise idle (a burst of them stalls the wave: the path takes 64 B/clk per CU): the small matrices
-    //      of the following products (L2 -> VGPR, fragment order), then the transposed ones of the backward products,
-    //      then -- last, because loads retire in order and these are random 832-byte rows from HBM -- the next
-    //      minibatch's rows, parked in the staging buffer during the weight-gradient phase.
+    //      of the following products (L2 -> VGPR, fragment order), then the transposed ones of the backward products.
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.packed), (short)0,
                                                                          p.pack_floats * 4, 0x00020000);
     const int lane16 = lane * 16;
@@ -1075,8 +1057,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     float4 wl[4];                            // W_last fragments [k tile]
     float4 wlt[4];                           // W_last^T [hidden tile]
     float4 wht[NL > 1 ? NL - 1 : 1][4][4];   // W_l^T [in tile][out tile]
-    float4 vnext[NLD];
-    constexpr int NH = (NL - 1) * 16, NREQ = 2 * NH + 8 + NLD, PERG = (NREQ + G0 - 1) / G0;
+    constexpr int NH = (NL - 1) * 16, NREQ = 2 * NH + 8, PERG = (NREQ + G0 - 1) / G0;
 
     // ---- layer 0: z^T[64 units][16 samples] = b0 + W0 X^T; lane quarter q walks features q*LQ .. q*LQ+LQ-1.
     //      Operands of group g+1 (4 fragment blocks + 4 features, LDS) are requested among the 16 MFMAs of group g:
@@ -1108,9 +1089,6 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
                 else if (j < 2 * NH + 8) {
                     const int k = j - NH - 8;   // (l-1)*16 + ti*4 + to
                     wht[k / 16][(k >> 2) & 3][k & 3] = ldw(p.pk_wht, k);
-                } else if (j < NREQ) {
-                    const int u = j - 2 * NH - 8;
-                    vnext[u] = *reinterpret_cast<const float4*>(A.rows + (size_t)nx_pix[u] * p.RP + 4 * nx_col[u]);
                 }
             }
             const float bx[4] = {bq[g & 1].x, bq[g & 1].y, bq[g & 1].z, bq[g & 1].w};
@@ -1329,19 +1307,6 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     if (nt < NF) strip(nt, 52);
     __builtin_amdgcn_sched_barrier(0);
     STAMP(10);
-    if (do_next) {   // park the next minibatch's rows, contiguous, written through
-        float* dst = A.stage_out + (size_t)(first + 16 * w) * p.RP;   // (w is scalar: a uniform descriptor)
-        const WtBuf stw(dst, (size_t)16 * p.RP * 4);
-#pragma unroll
-        for (int u = 0; u < NLD; ++u) {
-            const int c = min(lane + 64 * u, nchunk - 1);   // (past the end: the last chunk again, same data)
-#ifdef LBDRN_STAGE_PLAIN
-            stw.store_plain(4 * c, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
-#else
-            stw.store(4 * c, vnext[u].x, vnext[u].y, vnext[u].z, vnext[u].w);
-#endif
-        }
-    }
     // hidden layers' operands (strip w of H_{l-1}, the four unit tiles of dz_l): requested under the tail's MFMAs
     float a1[NL > 1 ? NL - 1 : 1][4][16], bh[NL > 1 ? NL - 1 : 1][16];
 #pragma unroll
@@ -1557,7 +1522,7 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
     A.stamps = nullptr;
 #ifdef LBDRN_TRAIN_STAMPS
     const int max_wg = (bs + TB - 1) / TB;
-    LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 4 * 16 * sizeof(unsigned long long)));
+    LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 8 * 16 * sizeof(unsigned long long)));
 #endif
     if (A.p.wave)
         if (int rc = configure_wave_kernel(A.p, net.nl)) return rc;
@@ -1573,6 +1538,7 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
         const int64_t nextB = std::max<int64_t>(0, std::min<int64_t>(bs, n - first - bs));
         A.stage_in = si > 0 ? stage[si & 1] : nullptr;          // staged by the previous launch
         A.stage_out = nextB > 0 ? stage[(si + 1) & 1] : nullptr;
+        if (A.p.wave) A.stage_in = nullptr, A.stage_out = nullptr;   // the wave-local kernel gathers for itself
         A.perm_next = perm + first + bs;
         A.next_n = (int)nextB;
         if (int rc = dispatch_train(A, nwg, s)) return rc;

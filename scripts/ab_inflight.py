@@ -12,7 +12,7 @@ tiles = [ops.to_device_u16(synthetic_tile(i, 8, 2048, 2048), dev) for i in range
 args = (5, 2, 64, 2, 1e-3, 8192, 10)
 out = []
 for infl in [int(x) for x in os.environ.get('AB_INFLIGHT', '1,2').split(',')]:
-    codec.fit_many(tiles[:2], *args, seed=19920517, in_flight=infl)
+    codec.fit_many(tiles[:max(2, infl)], *args, seed=19920517, in_flight=infl)   # every in-flight stream warm
     torch.cuda.synchronize(); t = time.perf_counter()
     fits = codec.fit_many(tiles, *args, seed=19920517, in_flight=infl)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / len(tiles)
