@@ -7,8 +7,9 @@
 A "step" is one pass of the hot path over one synthetic tile: the fused fit (bit split, 10 epochs of
 minibatch Adam with a whole-image evaluation after each, best-epoch selection), the 16-bit weight
 truncation the bitstream applies, and the fused apply (reconstruction).  The K tiles of the timed region are
-independent fits; --in-flight of them (default 2) progress at a time on each GPU, on their own streams,
-which fills the idle gaps of one fit's chain of short dependent kernels.  Each rank owns its own
+independent fits; --in-flight of them (default 4) progress at a time on each GPU, on their own streams: one
+fit's training step occupies half the chip (128 workgroups), so two steps of different fits run side by side while the
+reduce / evaluation / permutation kernels of the others fill the rest.  Each rank owns its own
 tiles (images are independent fits): weak scaling, no data-path collective; RCCL
 carries only the max-over-ranks time and the per-image metric records.  Inputs are resident in HBM
 when the timed region starts; host work that belongs to the path (the permutations of
@@ -37,7 +38,7 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None,
-                   help="timed tiles per GPU (default 4; 8 at --gpus 8 = the 64-tile job of BASELINE.json configs[3])")
+                   help="timed tiles per GPU (default 8: at --gpus 8 the 64-tile job of BASELINE.json configs[3])")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--height", type=int, default=2048)
     p.add_argument("--width", type=int, default=2048)
@@ -52,7 +53,7 @@ def parse():
     p.add_argument("--path", choices=["auto", "generic", "mfma"], default="auto")
     p.add_argument("--coords-embedding", action="store_true",
                    help="BASELINE.json configs[4]: USE_COORDINATES=True + EMBEDDING=True (F = 250)")
-    p.add_argument("--in-flight", type=int, default=2,
+    p.add_argument("--in-flight", type=int, default=4,
                    help="tiles progressing at a time on each GPU (independent fits on their own streams)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline crop")
@@ -60,7 +61,7 @@ def parse():
                    help="epochs of the recipe the CPU baseline runs on its crop (scaled to the full recipe)")
     a = p.parse_args()
     if a.steps is None:
-        a.steps = 8 if a.gpus == 8 else 4
+        a.steps = 8
     return a
 
 

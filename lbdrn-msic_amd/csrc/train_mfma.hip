@@ -1570,8 +1570,8 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
             t1max = std::max(t1max, h[k * 16 + 15]);
         }
         fprintf(stderr, "[lbdrn stamps, wave kernel] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
-                        "mean cycles: W0 DMA + rows->LDS %.0f | barrier 1 %.0f | small-matrix requests + layer0 %.0f | barrier 2 + W^T/next-row requests %.0f | "
-                        "act0 %.0f | hidden+act %.0f | out+loss %.0f | backward %.0f | barrier 3 %.0f | dW0 strips %.0f | park rows, dW tail+hidden %.0f | "
+                        "mean cycles: W0 DMA + rows->LDS %.0f | barrier 1 %.0f | small-matrix requests + layer0 %.0f | barrier 2 %.0f | "
+                        "act0 %.0f | hidden+act %.0f | out+loss %.0f | backward %.0f | barrier 3 %.0f | dW0 strips %.0f | dW tail+hidden %.0f | "
                         "bias sums %.0f | drain %.0f\n",
                 clk / nw, span / nw, (double)(t1max - t0min) / 100.0, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw, d[5] / nw, d[6] / nw,
                 d[7] / nw, d[8] / nw, d[9] / nw, d[10] / nw, d[11] / nw, d[12] / nw, d[13] / nw);

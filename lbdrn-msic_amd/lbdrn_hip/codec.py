@@ -162,24 +162,20 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
 
 
 def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-             path=ops.PATH_AUTO, seed=19920517, in_flight=2, then=None, draws=None):
+             path=ops.PATH_AUTO, seed=19920517, in_flight=None, then=None, draws=None):
     """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time, each on
-    its own stream and host thread (in_flight=None: 2, or 4 when the minibatches are too small to fill the
-    GPU); returns [then(fit) or fit, ...] in input order.
+    its own stream and host thread (in_flight=None: 4); returns [then(fit) or fit, ...] in input order.
 
-    Why: one fit is a strict chain of short dependent kernels (train 19 us -> reduce/Adam 5 us -> train ...),
-    so ramp, drain and the kernel boundaries of one image leave the chip idle a quarter of the time; a second
-    independent chain fills those holes (measured: 158 -> 108 ms per 8 x 2048^2 tile).  Images are independent
+    Why: one fit is a strict chain of short dependent kernels (train 20 us on half the chip -> reduce/Adam 5 us
+    -> train ...); independent chains side by side fill the other half and the holes (measured per 8 x 2048^2
+    tile: 157 ms alone, 98 with two, 84 with four in flight; more adds nothing).  Images are independent
     fits and every fit seeds the generator itself (`seed`, what each encode.py invocation does,
     ref encode.py:200-205), so results are bit-identical to fitting them one after another.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
     coding, ...).  `draws`: one FitDraws per image instead of `seed` (the tiles of one image, whose draws the
     caller made in tile order).  Returns after all streams have been joined to the caller's current stream."""
     if in_flight is None:
-        # a minibatch of >= 8192 rows puts a training workgroup on every CU: two chains saturate the GPU, more add
-        # nothing; smaller minibatches (small tiles) leave CUs free for further chains
-        rows = min(batch_size, min(int(t.shape[1]) * int(t.shape[2]) for t in images)) if images else batch_size
-        in_flight = 2 if rows >= 8192 else 4
+        in_flight = 4
     if draws is not None:
         seed = None
         if len(draws) != len(images):
@@ -291,7 +287,7 @@ def fit_image(img, K, D, base_channel, num_layers, lr, batch_size, epochs, val_d
 
 
 def fit_images(imgs, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-               device="cuda:0", path=ops.PATH_AUTO, host_msb=True, draws=None, seed=None, in_flight=2):
+               device="cuda:0", path=ops.PATH_AUTO, host_msb=True, draws=None, seed=None, in_flight=None):
     """fit_image for several rasters with `in_flight` of them progressing at a time on the GPU (fit_many).
     Either every fit seeds itself (`seed`: independent images, one encode.py invocation each in the reference)
     or the caller brings the draws it made in order (`draws`: the tiles of one image, ref encode.py:231-262)."""
