@@ -13,6 +13,7 @@
  *    lbdrn_last_error() returns a per-thread message for the last failure.
  *  - all data pointers are caller-owned DEVICE pointers (HBM); the library never frees or
  *    retains them.  Scalars and the two config structs are passed by value / host pointer.
+ *    (One exception, named where it is declared: the weight payload codec works on host buffers.)
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default
  *    stream) and re-entrant; there is no global mutable state besides the error string.
  *  - there is no CPU path: without a gfx950 device every compute call returns LBDRN_E_DEVICE.
@@ -162,6 +163,22 @@ int lbdrn_plane_encode(const uint16_t *planes, int32_t C, int32_t H, int32_t W, 
                        uint64_t *body_bytes, void *workspace, size_t workspace_bytes, void *stream);
 int lbdrn_plane_decode(const void *body, size_t body_bytes, int32_t C, int32_t H, int32_t W, uint16_t *planes,
                        int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Weight payload -- stands where the reference calls fpzip (encode.py:129 `fpzip.compress(params,
+ * precision=args.precision, order='C')`, decode.py:113 `fpzip.decompress(...)[0][0][0]`): the float32 parameter
+ * vector (state_dict order, a10) as a 1-D fpzip stream at `precision` bits (2..32; 0 = 32).  The lossy value map is
+ * "keep the top `precision` bits of the IEEE pattern".  fpzip's source is absent here: the stream syntax is a
+ * restatement of the published algorithm, PARITY UNPINNED (csrc/weights_codec.hip says what is and is not verified).
+ * A 35 KB serial entropy code runs on the host: these three calls take HOST pointers (the only ones in this header).
+ *   lbdrn_weights_bound   buffer size that always suffices for n values
+ *   lbdrn_weights_encode  writes the stream, *nbytes = its length
+ *   lbdrn_weights_info    reads the header: *n values at *precision bits
+ *   lbdrn_weights_decode  values[0..n) (capacity in values); LBDRN_E_ARG for a foreign or truncated stream */
+size_t lbdrn_weights_bound(int64_t n);
+int lbdrn_weights_encode(const float *values, int64_t n, int32_t precision, void *out, size_t capacity,
+                         size_t *nbytes);
+int lbdrn_weights_info(const void *stream, size_t nbytes, int64_t *n, int32_t *precision);
+int lbdrn_weights_decode(const void *stream, size_t nbytes, float *values, int64_t capacity);
 
 /* a7/a8 building block exposed for teacher-forced parity tests: one update on an explicit
  * minibatch x[B][F], t[B][C]; grads (optional) receives d(loss)/d(params). */

@@ -11,7 +11,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = ["cabi.hip", "generic.hip", "apply_mfma.hip", "train_mfma.hip", "randperm.hip", "plane_codec.hip"]
+SRCS = ["cabi.hip", "generic.hip", "apply_mfma.hip", "train_mfma.hip", "randperm.hip", "plane_codec.hip", "weights_codec.hip"]
 HDRS = ["common.hpp", "lbdrn_math.hpp", "../../include/lbdrn_hip.h"]
 OUT = os.path.join(os.path.dirname(HERE), "liblbdrn_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",

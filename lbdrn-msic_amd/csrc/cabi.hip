@@ -24,6 +24,10 @@ int plane_decode(const void* body, size_t body_bytes, int C, int H, int W, uint1
                  size_t ws_bytes, hipStream_t s);
 int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, void* ws, size_t ws_bytes,
                    hipStream_t s);
+size_t weights_bound(int64_t n);
+int weights_encode(const float* values, int64_t n, int precision, uint8_t* out, size_t cap, size_t* nbytes);
+int weights_info(const uint8_t* in, size_t nbytes, int64_t* n, int* precision);
+int weights_decode(const uint8_t* in, size_t nbytes, float* values, int64_t cap);
 }  // namespace lbdrn
 
 using namespace lbdrn;
@@ -272,6 +276,30 @@ int lbdrn_plane_decode(const void* body, size_t body_bytes, int32_t C, int32_t H
     LBDRN_REQUIRE(C >= 1 && H >= 1 && W >= 1 && C <= 65535, "bad raster geometry");
     NEED_DEVICE();
     return plane_decode(body, body_bytes, C, H, W, planes, status, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t lbdrn_weights_bound(int64_t n) { return n < 0 ? 0 : weights_bound(n); }
+
+int lbdrn_weights_encode(const float* values, int64_t n, int32_t precision, void* out, size_t capacity, size_t* nbytes)
+{
+    LBDRN_REQUIRE((values || n == 0) && out && nbytes && n >= 0 && n < ((int64_t)1 << 32), "null pointer or bad count");
+    LBDRN_REQUIRE(precision == 0 || (precision >= 2 && precision <= 32), "precision %d is not 0 or 2..32", precision);
+    return weights_encode(values, n, precision, (uint8_t*)out, capacity, nbytes);
+}
+
+int lbdrn_weights_info(const void* stream, size_t nbytes, int64_t* n, int32_t* precision)
+{
+    LBDRN_REQUIRE(stream && n && precision, "null pointer");
+    int prec = 0;
+    const int rc = weights_info((const uint8_t*)stream, nbytes, n, &prec);
+    *precision = prec;
+    return rc;
+}
+
+int lbdrn_weights_decode(const void* stream, size_t nbytes, float* values, int64_t capacity)
+{
+    LBDRN_REQUIRE(stream && (values || capacity == 0) && capacity >= 0, "null pointer or bad capacity");
+    return weights_decode((const uint8_t*)stream, nbytes, values, capacity);
 }
 
 int lbdrn_train_step(const lbdrn_net* net, const float* x, const float* t, int32_t B, float* params,

@@ -57,6 +57,10 @@ SIGNATURES = {
     "lbdrn_plane_workspace": (_sz, [_i32, _i32, _i32]),
     "lbdrn_plane_encode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _sz, _vp]),
     "lbdrn_plane_decode": (ctypes.c_int, [_vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "lbdrn_weights_bound": (_sz, [_i64]),
+    "lbdrn_weights_encode": (ctypes.c_int, [_vp, _i64, _i32, _vp, _sz, ctypes.POINTER(ctypes.c_size_t)]),
+    "lbdrn_weights_info": (ctypes.c_int, [_vp, _sz, ctypes.POINTER(_i64), ctypes.POINTER(_i32)]),
+    "lbdrn_weights_decode": (ctypes.c_int, [_vp, _sz, _vp, _i64]),
     "lbdrn_train_step": (ctypes.c_int, [_NP, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _dbl, _i32, _vp,
                                         _vp, _vp, _sz, _vp]),
 }

@@ -4,11 +4,14 @@ Header layout (ref encode.py:37-64, decode.py:25-53), big-endian:
   hdr_len:u8  split_ratio:u8  width:u16  height:u16  (K<<4)|D:u8  (log2(bc)<<4)|nl:u8
   nn_bytes:u24 x sr^2   base_bytes:u32 x sr^2
 The two payload codecs of the reference are third-party programs that are absent from this image
-(fpzip 1.2.4 for the weights, GDAL/OpenJPEG lossless JP2 for the MSB plane).  When they are
-importable they are used, which gives bitstreams the reference can read; otherwise private,
-clearly tagged payloads are written (see the two *_PRIVATE_MAGIC tags): the container layout is
-the reference's, the payload bytes are not.  DESIGN.md "Container" states what is and is not
-interchangeable.
+(fpzip 1.2.4 for the weights, GDAL/OpenJPEG lossless JP2 for the MSB plane).
+  * weights: an fpzip stream -- fpzip's own when the module is importable, otherwise written / read by this
+    package's restatement of the published algorithm (csrc/weights_codec.hip; byte compatibility with fpzip is
+    unverified: parity unpinned);
+  * MSB plane: always this package's own tagged format (LBB2, coded on the GPU; LBB1, the older host codec): JPEG 2000
+    syntax is not produced or read, with or without GDAL.  bpsp figures are therefore not comparable with the
+    reference's published ones; MSE / PSNR are.
+DESIGN.md "Container" states what is and is not interchangeable.
 """
 import lzma
 import struct
@@ -83,9 +86,13 @@ def unflatten_state(flat, like_state_dict):
 
 
 def truncate_precision(flat, precision):
-    """This package's model of fpzip's lossy mode: keep the `precision` most significant bits of
-    each float32 (sign, exponent, leading mantissa bits), clear the rest.  NOT verified against
-    fpzip itself (absent here); precision 0 or 32 = lossless."""
+    """The value map of the weight payload: keep the `precision` most significant bits of each float32 pattern
+    (sign, exponent, leading mantissa bits), clear the rest; precision 0 or 32 = lossless.  This IS fpzip's lossy
+    mode as its published algorithm defines it -- the order-preserving integer map drops the 32-precision low bits
+    of the (complemented) pattern and its inverse restores them as zeros, for every input alike: negative numbers,
+    both zeros, denormals, infinities, NaNs (a NaN whose payload sits only in the dropped bits becomes an infinity)
+    -- restated in csrc/weights_codec.hip and oracle/fpz_port.py.  Not checked against an fpzip build (absent here):
+    parity unpinned."""
     if precision in (0, 32):
         return flat.astype(np.float32).copy()
     if not 2 <= precision < 32:
@@ -94,42 +101,59 @@ def truncate_precision(flat, precision):
     return (flat.astype(np.float32).view(np.uint32) & mask).view(np.float32)
 
 
-def encode_weights(flat, precision):
-    flat = np.ascontiguousarray(flat, dtype=np.float32)
+def _fpzip_module():
     try:
-        import fpzip  # reference-compatible stream when the codec exists (ref encode.py:129)
-        return fpzip.compress(flat, precision=precision, order="C")
+        import fpzip
+        return fpzip
     except ImportError:
-        pass
-    q = truncate_precision(flat, precision).view(np.uint32)
-    nbytes = 4 if precision in (0, 32) else (precision + 7) // 8
-    planes = [((q >> (24 - 8 * i)) & 0xFF).astype(np.uint8).tobytes() for i in range(nbytes)]
-    body = zlib.compress(b"".join(planes), 9)
-    return NN_PRIVATE_MAGIC + struct.pack(">BI", precision, flat.size) + body
+        return None
+
+
+def encode_weights(flat, precision):
+    """The float32 parameter vector as a 1-D fpzip stream (ref encode.py:129).  With the fpzip module installed it
+    is fpzip's own output; otherwise the stream is written by lbdrn_weights_encode, this package's restatement of
+    the published algorithm (same syntax as far as can be known here: parity unpinned)."""
+    flat = np.ascontiguousarray(flat, dtype=np.float32)
+    fpzip = _fpzip_module()
+    if fpzip is not None:
+        return fpzip.compress(flat, precision=precision, order="C")
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    cap = L.lbdrn_weights_bound(flat.size)
+    out = (ctypes.c_uint8 * cap)()
+    nbytes = ctypes.c_size_t()
+    _lib.check(L.lbdrn_weights_encode(flat.ctypes.data_as(ctypes.c_void_p), flat.size, int(precision), out, cap,
+                                      ctypes.byref(nbytes)))
+    return bytes(out[:nbytes.value])
 
 
 def decode_weights(buf):
-    if buf[:4] != NN_PRIVATE_MAGIC:
-        import fpzip  # a stream written by the reference (ref decode.py:113)
-        return np.asarray(fpzip.decompress(bytes(buf), order="C")[0][0][0], dtype=np.float32)
-    precision, count = struct.unpack_from(">BI", buf, 4)
-    nbytes = 4 if precision in (0, 32) else (precision + 7) // 8
-    raw = np.frombuffer(zlib.decompress(bytes(buf[9:])), np.uint8).reshape(nbytes, count)
-    q = np.zeros(count, np.uint32)
-    for i in range(nbytes):
-        q |= raw[i].astype(np.uint32) << np.uint32(24 - 8 * i)
-    return q.view(np.float32)
+    """Weight payload -> float32 vector (ref decode.py:113).  Streams of earlier builds (tag LBW1: byte planes +
+    zlib) still decode."""
+    buf = bytes(buf)
+    if buf[:4] == NN_PRIVATE_MAGIC:
+        precision, count = struct.unpack_from(">BI", buf, 4)
+        nbytes = 4 if precision in (0, 32) else (precision + 7) // 8
+        raw = np.frombuffer(zlib.decompress(buf[9:]), np.uint8).reshape(nbytes, count)
+        q = np.zeros(count, np.uint32)
+        for i in range(nbytes):
+            q |= raw[i].astype(np.uint32) << np.uint32(24 - 8 * i)
+        return q.view(np.float32)
+    fpzip = _fpzip_module()
+    if fpzip is not None:
+        return np.asarray(fpzip.decompress(buf, order="C")[0][0][0], dtype=np.float32)
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    n, prec = ctypes.c_int64(), ctypes.c_int32()
+    _lib.check(L.lbdrn_weights_info(buf, len(buf), ctypes.byref(n), ctypes.byref(prec)))
+    out = np.empty(n.value, np.float32)
+    _lib.check(L.lbdrn_weights_decode(buf, len(buf), out.ctypes.data_as(ctypes.c_void_p), out.size))
+    return out
 
 
 # ---------------------------------------------------------------- MSB-plane payload
-
-def _have_gdal_jp2():
-    try:
-        from osgeo import gdal
-        return gdal.GetDriverByName("JP2OpenJPEG") is not None
-    except Exception:
-        return False
-
 
 def encode_base(msb, codec="LBB2", device="cuda:0", as_uint8=None):
     """Lossless MSB plane [C,H,W] (uint8 when max <= 255 else uint16, ref LBDRNdataset.py:100); stands where

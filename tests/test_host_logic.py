@@ -148,6 +148,50 @@ def test_positional_tables_equal_reference_features(golden):
     assert np.array_equal(rt[:, 0], f[:, 0, 0]) and np.array_equal(ct[:, 0], f[0, :, 1])
 
 
+def test_weight_payload_value_map_on_every_class_of_float():
+    """truncate_precision (the lossy value map of the weight payload, ref encode.py:129 precision=16) on negative
+    numbers, both zeros, denormals, infinities and NaNs, and the same map through the fpzip-syntax stream of the C
+    ABI (lbdrn_weights_encode / _decode) and through the independent Python restatement (oracle/fpz_port.py):
+    identical bits from all three, identical stream bytes from the two coders."""
+    import fpz_port as FP
+    from lbdrn_hip import container as c
+    special = np.array([0x00000000, 0x80000000,              # +0, -0
+                        0x00000001, 0x80000001, 0x007FFFFF,  # denormals
+                        0x00800000, 0x3F800000, 0xBF800000,  # smallest normal, +-1
+                        0x3F80FFFF, 0xBF80FFFF, 0x3F810000,  # just below / at a kept-bit boundary
+                        0x7F7FFFFF, 0xFF7FFFFF,              # +-max
+                        0x7F800000, 0xFF800000,              # +-inf
+                        0x7FC00000, 0xFFC00000, 0x7F800001, 0x7FBFFFFF,   # quiet NaN, NaNs with low payloads
+                        0x12345678, 0x87654321], np.uint32)
+    w = special.view(np.float32)
+    t16 = c.truncate_precision(w, 16).view(np.uint32)
+    assert np.array_equal(t16, special & np.uint32(0xFFFF0000))          # sign-magnitude truncation, every class
+    assert t16[0] == 0 and t16[1] == 0x80000000                            # the sign of zero survives
+    assert t16[2] == 0 and t16[4] == 0x007F0000                            # denormals: truncated like anything else
+    assert t16[17] == 0x7F800000 and np.isinf(t16[17:18].view(np.float32))[0]   # NaN payload in dropped bits -> inf
+    assert np.isnan(t16[15:17].view(np.float32)).all()                      # quiet NaNs stay NaN
+    rng = np.random.default_rng(5)
+    big = np.concatenate([w, rng.normal(0, 0.05, 5000).astype(np.float32), np.zeros(40, np.float32)])
+    for prec in (16, 2, 9, 24, 32, 0):
+        stream = c.encode_weights(big, prec)
+        bits = big.view(np.uint32)
+        expect = c.truncate_precision(big, prec).view(np.uint32)
+        assert stream == FP.compress(bits.tolist(), prec), prec               # two independent coders, same bytes
+        assert np.array_equal(c.decode_weights(stream).view(np.uint32), expect), prec
+        got, p = FP.decompress(stream)
+        assert p == (prec or 32) and np.array_equal(np.array(got, np.uint32), expect), prec
+        assert np.array_equal(np.array([FP.truncate_bits(int(b), prec or 32) for b in bits], np.uint32), expect)
+    # foreign and damaged streams are refused, not decoded into garbage lengths
+    from lbdrn_hip import _lib
+    good = c.encode_weights(big, 16)
+    for bad in (b"", b"JUNKJUNKJUNK", good[:6]):
+        with pytest.raises(_lib.LbdrnError):
+            c.decode_weights(bad)
+    with pytest.raises(_lib.LbdrnError):
+        c.decode_weights(good[:len(good) // 2])
+    assert c.decode_weights(c.encode_weights(np.zeros(0, np.float32), 16)).size == 0
+
+
 def test_payload_round_trips_and_precision_model():
     from lbdrn_hip import container as c
     rng = np.random.default_rng(0)
