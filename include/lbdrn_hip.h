@@ -130,7 +130,8 @@ int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t 
                       double lr, float *losses, void *workspace, size_t workspace_bytes,
                       int32_t path, void *stream);
 
-/* Measurement aid (bench.py roofline leg).  mode 1: every step of lbdrn_train_epoch on this thread
+/* DIAGNOSTIC, not part of the codec path: a measurement aid of bench.py's roofline leg, and the one piece of mutable
+ * state this library keeps besides the error string -- thread-local, off (0) unless a caller sets it.  mode 1: every step of lbdrn_train_epoch on this thread
  * launches its reduce/Adam kernel twice (the second with a zero step size), mode 0: normal.  Timing one
  * epoch in each mode with a single HIP-event pair gives t_reduce = t(mode 1) - t(mode 0) per step and
  * t_train_kernel = t(mode 0) - t_reduce, both inside the real launch sequence and without per-launch event

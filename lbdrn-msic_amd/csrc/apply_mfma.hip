@@ -18,6 +18,8 @@
 //    conflict-free ds_read_b64; the D-ring of normalised MSB values is staged per 16x64 tile in
 //    channel-planar LDS (conflict-free for 32 consecutive pixels) with reflect padding applied.
 //  * 8 waves per CU (2 per SIMD): one wave's sin() VALU work overlaps the other's MFMAs.
+#include <atomic>
+
 #include "common.hpp"
 #include "lbdrn_math.hpp"
 
@@ -440,12 +442,15 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
     }
 }
 
+// one wave: lane l sums partial[l], partial[l + 64], .. in index order, then the 64 lane sums pairwise in a fixed tree
+// (the same value every run; a single thread walking 256 partials took 13 us)
 __global__ void k_sum_partials_mfma(const double* __restrict__ partial, int n, double* dst)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     double s = 0.0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    *dst = s;
+    for (int i = lane; i < n; i += 64) s += partial[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) *dst = s;
 }
 
 template <int NT, int MODE>
@@ -453,8 +458,17 @@ static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s)
 {
     const size_t lds_bytes = (size_t)A.p.lds_floats * 4;
     auto kern = k_apply_mfma<NT, MODE>;
-    LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // the kernel may use the whole 160 KB of a CU's LDS: told to the runtime once per device and kernel (a cache of an
+    // idempotent setting, not state a caller can observe)
+    static std::atomic<unsigned long long> configured{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured.load(std::memory_order_relaxed) & bit)) {
+        LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured.fetch_or(bit, std::memory_order_relaxed);
+    }
     kern<<<grid, APPLY_THREADS, lds_bytes, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;

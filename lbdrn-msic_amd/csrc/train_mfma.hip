@@ -34,6 +34,7 @@
 //
 // Training parity is a tolerance contract (1e-5 relative on the loss), not a bit
 // pattern: the summation order differs from the generic kernels and from torch.
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -1384,11 +1385,15 @@ static int launch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
     auto kern = k_train_mfma<LQ, NL>;
     const size_t lds_bytes = (size_t)A.p.lds_floats * 4;
-    static thread_local size_t configured = 0;
-    if (configured < lds_bytes) {
+    // told to the runtime once per device and kernel (a cache of an idempotent setting)
+    static std::atomic<unsigned long long> configured{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured.load(std::memory_order_relaxed) & bit)) {
         LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        configured = lds_bytes;
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured.fetch_or(bit, std::memory_order_relaxed);
     }
     kern<<<nwg, TRAIN_THREADS, lds_bytes, s>>>(A);
     LBDRN_LAUNCH_CHECK();

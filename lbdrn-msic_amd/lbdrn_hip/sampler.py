@@ -9,7 +9,6 @@ so the global generator is consumed train, eval, train, eval, ...  This module r
 those draws with the same torch calls; only the permutation is then shipped to the GPU instead
 of 4.19 M Python-level __getitem__ calls per pass (ref LBDRNdataset.py:151-155).
 """
-from concurrent.futures import ThreadPoolExecutor
 
 import torch
 
@@ -48,7 +47,7 @@ def draw_pass_seeds(plan):
 
 
 class DevicePermutationStream:
-    """Same draws as PermutationStream; the permutations are computed on the GPU by lbdrn_randperm (the
+    """The permutations of a fit's training passes, computed on the GPU by lbdrn_randperm (the
     exact torch.randperm sequences).  The MT19937 recurrence is serial (5 ms for 4 M words, whatever the
     number of seeds generated side by side), so the work runs on a side stream in two batches -- epoch 1
     alone, then all the others -- and the training stream only waits for the batch it needs: the first
@@ -100,34 +99,3 @@ def _side_stream(device):
 
 
 GPU_RANDPERM_MAX = 0xFFFFFFFF // 20  # torch's randperm switches algorithm above this
-
-
-class PermutationStream:
-    """Host-side twin of DevicePermutationStream (torch.randperm on worker threads).  Not used by the fit:
-    it is the form the CPU tests compare with a real DataLoader, and what the GPU stream is checked against.
-
-    Draws every pass's seed up front (the global generator is touched by nothing else during the
-    fit) and computes the train permutations on worker threads so that the host-side Fisher-Yates
-    (0.1-0.3 s for 4 M indices) overlaps the GPU work of earlier epochs."""
-
-    def __init__(self, n, epochs, val_duration, workers=4, pin=True):
-        self.n = n
-        self.plan = epoch_plan(epochs, val_duration)
-        self.seeds = {}
-        for kind, e in self.plan:
-            seed = draw_iterator_seed()
-            if kind == "train":
-                self.seeds[e] = seed
-        self._pool = ThreadPoolExecutor(max_workers=max(1, workers))
-        self._pin = pin and torch.cuda.is_available()
-        self._futs = {e: self._pool.submit(self._make, s) for e, s in sorted(self.seeds.items())}
-
-    def _make(self, seed):
-        p = permutation(seed, self.n)
-        return p.pin_memory() if self._pin else p
-
-    def get(self, epoch):
-        return self._futs.pop(epoch).result()
-
-    def close(self):
-        self._pool.shutdown(wait=False, cancel_futures=True)

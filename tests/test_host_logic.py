@@ -107,9 +107,9 @@ def test_sampler_replays_dataloader_draw_order():
         for _ in loader:                                  # evaluator pass (order irrelevant)
             pass
     torch.manual_seed(7)
-    st = sampler.PermutationStream(n, epochs, 1, workers=2, pin=False)
+    seeds = sampler.draw_pass_seeds(sampler.epoch_plan(epochs, 1))   # what a fit draws (codec.draw_fit)
     for e in range(1, epochs + 1):
-        assert torch.equal(st.get(e), want[e - 1])
+        assert torch.equal(sampler.permutation(seeds[e - 1], n), want[e - 1])
     assert sampler.epoch_plan(1, 1) == [("train", 1)]      # epochs == 1: no evaluation (encode.py:100)
     assert sampler.epoch_plan(4, 2) == [("train", 1), ("train", 2), ("eval", 2), ("train", 3), ("train", 4), ("eval", 4)]
     # after the stream the global generator sits where the DataLoader run left it
