@@ -97,10 +97,12 @@ def event_time_ms(fn, stream, repeat=1):
 
 
 def roofline_probe(codec, ops, fit, img_d, a, path):
-    """Live HIP-event timing, on the launch stream, right after the timed region (same process, same
-    tile).  Dominant kernel = the fused training kernel k_train_mfma (5120 launches per tile): every one of
-    its 512 launches in one real epoch (train, reduce/Adam, train, ...) is bracketed by its own event pair
-    (lbdrn_train_profile_begin/end).  The train+reduce pair and the fused apply kernel are reported beside it."""
+    """Live HIP-event timing, on the launch stream, right after the timed region (same process, same tile).
+    Dominant kernel = the fused training step k_train_wave (5120 launches per tile, 60 % of the GPU time of a fit):
+    one real 512-step epoch (train, reduce/Adam, train, ...) between one event pair, and one with every reduce
+    launch doubled (lbdrn_train_profile_mode) -- the difference isolates the reduce kernel, the rest of a step is the
+    train kernel (plus its launch gap).  The fused apply kernel is reported beside it.  Counter-derived fields
+    (traffic, mfma_busy_frac) come from the committed rocprofv3 --pmc summary of the same kernels."""
     stream = torch.cuda.current_stream()
     geom, net = fit.geom, fit.net
     N = geom.H * geom.W
@@ -112,32 +114,30 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     perm = torch.randperm(N, device=img_d.device)
     pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
     tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path)
-    t_epoch = event_time_ms(lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0,
-                                                    1e-6, None, path, tws), stream, 1)
+    run_epoch = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0, 1e-6, None, path, tws)
+    run_epoch()
+    t_epoch = event_time_ms(run_epoch, stream, 1)
     nsteps = (N + a.bs - 1) // a.bs
     peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
     B = min(a.bs, N)
     out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "traffic": None}
-    # the dominant kernel inside the real train/reduce sequence: one epoch with the reduce launch doubled
-    # isolates the reduce kernel (t2 - t1); the rest of a step is the train kernel (plus ~0.4 us of gap)
-    run_epoch = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0, 1e-6, None, path, tws)
     try:
         ops.train_profile_mode(1)
         t_epoch2 = event_time_ms(run_epoch, stream, 1)
     finally:
         ops.train_profile_mode(0)
     t_reduce = (t_epoch2 - t_epoch) / nsteps
-    if t_reduce > 0.5e-3:  # the MFMA path is in use (the generic path ignores the mode)
+    fused = t_reduce > 0.5e-3   # a fused MFMA train kernel is in use (the generic path ignores the mode)
+    if fused:
         t_k = t_epoch / nsteps - t_reduce
-        out.update({"kernel": "k_train_mfma (gather+forward+loss+backward+dW slab, one 8192-row minibatch)",
+        out.update({"kernel": "k_train_wave (row gather + forward + loss + backward + weight-gradient slab of one 8192-row "
+                              "minibatch: 128 workgroups of 64 rows, one per CU, on half of the chip's 256 CUs)",
                     "kernel_us": round(t_k * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
-                    "flop_per_launch": step * B,
-                    "timing": "HIP events over one 512-step epoch of ONE fit on the launch stream, and over one with the "
-                              "reduce launch doubled; kernel_us = step - reduce, inside the real launch sequence. "
-                              "rocprofv3 agrees on the same one-fit sequence (profiles/r01_final_kernel_stats_one_in_flight.csv: "
-                              "20.0 us); with two fits in flight (the timed region) a trace's per-launch durations also "
-                              "contain the other fit's co-running reduce kernels (..._two_in_flight.csv: 24.4 us)"})
-    else:  # shape without an MFMA train kernel: the generic step is many launches
+                    "flop_per_launch": step * B, "cus_occupied": min(256, (B + 63) // 64),
+                    "timing": "HIP events over one 512-step epoch of ONE fit on the launch stream, and over one with the reduce "
+                              "launch doubled; kernel_us = step - reduce (it contains the launch gap).  rocprofv3 --kernel-trace of "
+                              "the one-fit sequence: profiles/*_kernel_stats_one_in_flight.csv"})
+    else:  # shape without a fused train kernel: the generic step is many launches
         t_k = t_epoch / nsteps
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
     ach = step * B / (t_k * 1e-3) / 1e12
@@ -145,13 +145,22 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
                 "train_step_pair_us": round(t_epoch * 1e3 / nsteps, 2),
                 "train_step_pair_tflops": round(step * N / (t_epoch * 1e-3) / 1e12, 3),
                 "apply_pass_ms": round(t_eval, 3), "apply_tflops": round(fwd * N / (t_eval * 1e-3) / 1e12, 3),
+                "apply_frac": round(fwd * N / (t_eval * 1e-3) / 1e12 / peak, 4),
                 "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1)})
+    if fused:
+        # the kernel holds half of the chip (two fits' steps run side by side): the same rate against the peak of
+        # the CUs it occupies
+        out["frac_of_occupied_cus"] = round(ach / (peak * out["cus_occupied"] / 256.0), 4)
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")   # committed rocprofv3 --pmc summary, if any
-    if os.path.exists(pmc) and out["kernel"].startswith("k_train_mfma"):
+    if os.path.exists(pmc) and fused:
         try:
             d = json.load(open(pmc))
-            out["traffic"] = d.get("k_train_mfma_hbm_bytes_per_launch")
-            out["traffic_source"] = d.get("source")
+            out["traffic"] = d.get("k_train_wave_hbm_bytes_per_launch")
+            out["traffic_algorithmic_bytes"] = d.get("algorithmic_bytes_per_train_launch")
+            out["mfma_busy_frac"] = d.get("k_train_wave_mfma_busy_frac_whole_chip")
+            out["mfma_busy_frac_occupied_simds"] = d.get("k_train_wave_mfma_busy_frac_occupied_simds")
+            out["apply_mfma_busy_frac"] = d.get("k_apply_mfma_eval_mfma_busy_frac_whole_chip")
+            out["counters_source"] = d.get("source")
         except Exception:
             pass
     return out
@@ -363,6 +372,12 @@ def main():
             "records": records,
         }
         out["roofline"] = roofline_probe(codec, ops, fit, img_d, a, path)
+        # whole job against the matrix peak: algorithmic FLOPs of every timed tile (10 train + 10 evaluation passes + decode)
+        fwd_f, step_f = flops_per_pixel(fit.geom.F, fit.net.bc, fit.net.C, fit.net.nl)
+        evals = a.epochs if a.epochs > 1 else 0
+        tile_flop = px * (a.epochs * step_f + (evals + 1) * fwd_f)
+        out["roofline"]["end_to_end_tflops"] = round(tile_flop * a.steps * world / elapsed / 1e12, 3)
+        out["roofline"]["end_to_end_frac"] = round(tile_flop * a.steps / elapsed / 1e12 / 157.3, 4)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Profile pass of a round, run ON the GPU box (gpurun): scripts/profile_round.sh TAG [kt|pmc|sq ...]
+#   kt   rocprofv3 --kernel-trace --stats of bench.py with one fit in flight and with the default (four)
+#   pmc  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (--kernel-trace only) -> per-kernel mean bytes
+#   sq   two SQ counter passes (8 counters each) -> per-kernel means
+# Small CSVs land under gpurun_out/prof_TAG/; the databases are deleted as soon as they are summarised.
+TAG=${1:-r02}; shift
+WHAT=${@:-kt pmc sq}
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+CMD1="python3 bench.py --no-cpu-baseline --in-flight 1 --steps 1 --warmup 0"
+CMDP="python3 scripts/prof_fit.py 2048 64 4"   # counter passes: one fit at a time, 4 epochs x 2 fits (rocprofv3 --pmc dies past ~16 k dispatches)
+summarise() { # dir out-csv script [filters]
+  DB=$(find $1 -name "*.db" | head -1)
+  if [ -n "$DB" ]; then python $3 $DB $2 ${@:4} > ${2%.csv}.txt 2>&1; else echo "no database in $1" > ${2%.csv}.txt; fi
+  rm -rf $1
+}
+for W in $WHAT; do case $W in
+kt)
+  rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- $CMD1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
+  summarise $OUT/kt1 $OUT/kernel_stats_one_in_flight.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
+  summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py ;;
+pmc)
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o run -- $CMDP > /dev/null 2> $OUT/pmc_$C.err; echo "pmc $C rc=$?" >> $OUT/status.txt
+    summarise $OUT/pmc_$C $OUT/pmc_$C.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply k_build
+  done ;;
+sq)
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
+    -d $OUT/sq_a -o run -- $CMDP > /dev/null 2> $OUT/sq_a.err; echo "sq_a rc=$?" >> $OUT/status.txt
+  summarise $OUT/sq_a $OUT/sq_a.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
+  timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM \
+    -d $OUT/sq_b -o run -- $CMDP > /dev/null 2> $OUT/sq_b.err; echo "sq_b rc=$?" >> $OUT/status.txt
+  summarise $OUT/sq_b $OUT/sq_b.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply ;;
+esac; done
+ls -la $OUT; cat $OUT/status.txt 2>/dev/null

@@ -190,7 +190,8 @@ def test_cli_split_ratio_tiles(dev, tmp_path):
 
 
 def test_tiles_sharded_over_two_ranks_equal_the_serial_run(dev, tmp_path):
-    """torchrun with two ranks (both on this box's one GPU; eight GPUs work the same way): the 3x3 tiles of
+    """torchrun with two ranks (on a one-GPU box both share cuda:0 -- placement on distinct GPUs is the next test's
+    subject): the 3x3 tiles of
     an image fitted round-robin by the ranks give byte for byte the .bin of the single-process run -- the RNG
     replay of the tiles a rank skips included -- and the sharded decode reports the serial run's metrics.  Then
     the sweep driver over two K values on two ranks, summarised into the CSV."""
@@ -232,6 +233,33 @@ def test_tiles_sharded_over_two_ranks_equal_the_serial_run(dev, tmp_path):
     assert rows[0] == ["K", "scene_MSE", "scene_PSNR", "scene_bpsp", "scene_bits"]
     assert [r[0] for r in rows[1:]] == ["K3", "K4"] and all(float(x) > 0 for r in rows[1:] for x in r[1:])
     assert float(rows[1][1]) < float(rows[2][1])        # more bits kept exactly (smaller K) -> smaller error
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: ranks must land on distinct devices")
+def test_two_ranks_run_on_their_own_gpus(dev, tmp_path):
+    """On a node with >= 2 GPUs: rank r's fits, payload coding and decode run on cuda:r (the log names the device of
+    every fit; ops._call takes device and stream from the tensors), and the .bin equals the single-process one."""
+    img = synthetic_tile(17, 4, 40, 48)
+    src = tmp_path / "scene.tif"
+    raster_io.write_raster(str(src), img)
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    flags = ["-K", "4", "-D", "1", "-bs", "96", "-e", "2", "-sr", "2"]
+    pkg = os.path.join(ROOT, "lbdrn-msic_amd")
+    run2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+            "--master-addr", "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90)]
+    subprocess.run([sys.executable, os.path.join(pkg, "encode.py"), "-i", str(src), "-o", str(tmp_path / "one")] + flags,
+                   check=True, env=env, capture_output=True)
+    subprocess.run(run2 + [os.path.join(pkg, "encode.py"), "-i", str(src), "-o", str(tmp_path / "two")] + flags,
+                   check=True, env=env, capture_output=True, timeout=600)
+    sub = "scene_r2_K4_bc64_nl2_D1_prec16_lr0.001_bs96_e2"
+    assert (tmp_path / "one" / sub / "scene.bin").read_bytes() == (tmp_path / "two" / sub / "scene.bin").read_bytes()
+    log = (tmp_path / "two" / sub / "encode.txt").read_text()
+    assert log.count(" on cuda:0") == 2 and log.count(" on cuda:1") == 2      # four tiles, two per rank, own GPU each
+    subprocess.run(run2 + [os.path.join(pkg, "decode.py"), "-i", str(tmp_path / "two" / sub / "scene.bin"), "-org", str(src)],
+                   check=True, env=env, capture_output=True, timeout=600)
+    assert "PSNR" in (tmp_path / "two" / sub / "decode.txt").read_text()
 
 
 def test_full_size_properties(dev):
