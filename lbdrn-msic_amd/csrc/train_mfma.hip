@@ -157,10 +157,14 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     return true;
 }
 
+struct WidePlan;
+static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net);
+static size_t wide_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
+
 bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net)
 {
     TrainPlan p;
-    return make_train_plan(g, net, &p);
+    return make_train_plan(g, net, &p) || wide_supported(g, net);
 }
 
 struct TrainWsLayout {
@@ -187,7 +191,7 @@ static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, 
 size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 {
     TrainPlan p;
-    if (!make_train_plan(g, net, &p)) return 0;
+    if (!make_train_plan(g, net, &p)) return wide_workspace(g, net, bs);
     return train_ws_layout(g, net, p, bs).total;
 }
 
@@ -1378,6 +1382,20 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #endif
 }
 
+#include "train_wide.inc"
+
+static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    WidePlan p;
+    return make_wide_plan(g, net, &p);
+}
+static size_t wide_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
+{
+    WidePlan p;
+    if (!make_wide_plan(g, net, &p)) return 0;
+    return wide_ws_layout(g, net, p, bs).total;
+}
+
 // ------------------------------------------------------------------ host driver
 
 template <int LQ, int NL>
@@ -1464,16 +1482,25 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
                        const uint16_t* msb, int bs, void* ws, size_t ws_bytes, hipStream_t s)
 {
     TrainPlan p;
-    if (!make_train_plan(g, net, &p)) {
-        set_error("shape not supported by the MFMA train kernel");
-        return LBDRN_E_UNSUPPORTED;
+    size_t need = 0, off_rows = 0;
+    if (make_train_plan(g, net, &p)) {
+        const TrainWsLayout L = train_ws_layout(g, net, p, bs);
+        need = L.total; off_rows = L.off_rows;
+    } else {
+        WidePlan wp;
+        if (!make_wide_plan(g, net, &wp)) {
+            set_error("shape not supported by the MFMA train kernels");
+            return LBDRN_E_UNSUPPORTED;
+        }
+        const WideWsLayout L = wide_ws_layout(g, net, wp, bs);
+        need = L.total; off_rows = L.off_rows;
+        p.RP = wp.RP;
     }
-    const TrainWsLayout L = train_ws_layout(g, net, p, bs);
-    if (!ws || ws_bytes < L.total) {
-        set_error("train workspace too small: %zu < %zu", ws_bytes, L.total);
+    if (!ws || ws_bytes < need) {
+        set_error("train workspace too small: %zu < %zu", ws_bytes, need);
         return LBDRN_E_WORKSPACE;
     }
-    float* rows = (float*)((char*)ws + L.off_rows);
+    float* rows = (float*)((char*)ws + off_rows);
     const int64_t total = (int64_t)g.H * g.W * p.RP;
     LBDRN_REQUIRE((total + 255) / 256 < ((int64_t)1 << 31), "image too large for one launch");
     const int side = 2 * g.D + 1;
@@ -1502,10 +1529,8 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
                      size_t ws_bytes, hipStream_t s)
 {
     TrainArgs A;
-    if (!make_train_plan(g, net, &A.p)) {
-        set_error("shape not supported by the MFMA train kernel");
-        return LBDRN_E_UNSUPPORTED;
-    }
+    if (!make_train_plan(g, net, &A.p))
+        return wide_train_epoch(g, net, perm, n, bs, params, m, v, step0, lr, losses, ws, ws_bytes, s);
     const TrainWsLayout L = train_ws_layout(g, net, A.p, bs);
     if (!ws || ws_bytes < L.total) {
         set_error("train workspace too small: %zu < %zu", ws_bytes, L.total);

@@ -37,23 +37,27 @@ CASES = [
     (16, 20, 24, 6, 0, 2, 128, (0, 0, 1, 1)),     # D=0: F=C=16, all 16 output slots used
     (8, 24, 36, 5, 2, 2, 400, (1, 1, 1, 1)),      # F=250 (LQ=64): positional embedding, config 5
     (1, 31, 29, 4, 3, 2, 200, (1, 0, 1, 0)),      # one band, coords without embedding, absolute colours
+    (8, 40, 52, 5, 2, 2, 512, (0, 0, 1, 1), 256), # bc=256 (BASELINE configs[2]): the wide wave-local kernel, NT=16
+    (4, 30, 41, 5, 2, 1, 300, (0, 0, 1, 1), 128), # bc=128, one hidden layer (NT=8), ragged workgroups
+    (8, 24, 36, 5, 2, 2, 400, (1, 1, 1, 1), 256), # bc=256 with the positional embedding (F=250, LQ=64)
 ]
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_mfma_epoch_matches_generic_and_oracle(dev, case):
-    C, H, W, K, D, nl, bs, flags = case
+    C, H, W, K, D, nl, bs, flags = case[:8]
+    bc = case[8] if len(case) > 8 else 64
     rng = np.random.default_rng(sum(case[:7]))
     cfg = FeatCfg(bool(flags[0]), bool(flags[1]), 1.4, 12, bool(flags[2]), bool(flags[3]))
     ocfg = O.FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative)
     img = synthetic_tile(int(rng.integers(100)), C, H, W)
     msb, lab, mx = O.split_bits(img, K)
     F = cfg.feature_dim(C, D)
-    p0 = _params(rng, F, 64, C, nl)
+    p0 = _params(rng, F, bc, C, nl)
     perm_np = rng.permutation(H * W).astype(np.int64)
     perm = torch.from_numpy(perm_np).to(dev)
     geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
-    net = ops.make_net(F, 64, C, nl)
+    net = ops.make_net(F, bc, C, nl)
     img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
     nsteps = (H * W + bs - 1) // bs
     res = {}
@@ -69,26 +73,27 @@ def test_mfma_epoch_matches_generic_and_oracle(dev, case):
     lo = []
     for s in range(nsteps):
         b = perm_np[s * bs:(s + 1) * bs]
-        l, _ = O.train_step(po, mo, vo, F, 64, C, nl, feats[b], lab[b], 1e-3, 3 + s + 1)
+        l, _ = O.train_step(po, mo, vo, F, bc, C, nl, feats[b], lab[b], 1e-3, 3 + s + 1)
         lo.append(l)
     for path in (GEN, MFMA):
         p, m, v, losses = res[path]
         np.testing.assert_allclose(losses, np.array(lo), rtol=1e-5), path   # north_star tolerance
+        wide = 4.0 if bc > 64 else 1.0   # dots of 256 terms and 4x the partial sums: measured 4e-5 on the moments at bc = 256
         assert np.linalg.norm(p - po) <= 2e-5 * np.linalg.norm(po), path
-        assert np.abs(m - mo).max() <= 2e-5 * np.abs(mo).max(), path
-        assert np.abs(v - vo).max() <= 5e-5 * np.abs(vo).max(), path
+        assert np.abs(m - mo).max() <= wide * 2e-5 * np.abs(mo).max(), path
+        assert np.abs(v - vo).max() <= wide * 5e-5 * np.abs(vo).max(), path
 
 
 def test_mfma_train_rejects_unsupported_shapes(dev):
     img = synthetic_tile(1, 4, 16, 16)
     msb, _, mx = O.split_bits(img, 5)
     geom = ops.FeatureGeometry(4, 16, 16, 5, 2, mx, FeatCfg(), dev)
-    net = ops.make_net(100, 128, 4, 2)   # bc=128: generic only
+    net = ops.make_net(100, 32, 4, 2)    # bc=32: generic only (the fused steps take bc = 64, 128, 256)
     ws = ops.TrainWorkspace(geom, net, 64, dev)
     with pytest.raises(ops._lib.LbdrnError):
         ws.prepare(ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev), MFMA)
     # the generic path takes it
-    p = torch.from_numpy(_params(np.random.default_rng(0), 100, 128, 4, 2)).to(dev)
+    p = torch.from_numpy(_params(np.random.default_rng(0), 100, 32, 4, 2)).to(dev)
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     perm = torch.randperm(256, device=dev)
     ops.train_epoch(geom, net, ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev), perm, 64, p, m, v, 0, 1e-3)
