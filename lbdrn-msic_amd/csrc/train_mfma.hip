@@ -131,6 +131,10 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
         p.wave = net.nl <= 2 && p.RP <= xp && 16 * p.NT0 <= xp && (size_t)p.wave_lds_floats * 4 <= 160 * 1024;
         const char* force = getenv("LBDRN_TRAIN_KERNEL");     // "tile": the 8-wave tile kernel (A/B measurements)
         if (force && force[0] == 't') p.wave = 0;
+        // the wave-local kernel brings its rows in by LDS-DMA, which wants the matrix row pitch equal to the LDS row
+        // pitch (a wave's 16 rows are then one lane-linear piece): the row matrix is padded to it (config 1: 208 = 208;
+        // positional embedding, F = 250: 260 -> 272 floats, 4.6 % more rows traffic for a prologue without registers)
+        if (p.wave) p.RP = xp;
         const int rp4 = p.RP / 4;
         p.w_dp = 64 / rp4;
         p.w_df = 64 % rp4;
@@ -964,17 +968,17 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     // ---- rows: the wave copies its own 16 rows (16 * RP/4 chunks of 16 B, chunk c = lane + 64 u), gathered from the
     //      [N][RP] row matrix by pixel index (a staging buffer filled one launch ahead, as the tile kernel keeps, buys
     //      nothing here: with every request of the prologue in flight at once the gather lands as fast as a contiguous
-    //      read -- measured -- and it costs a gather, a store and a read of 6.8 MB per step).  When the LDS row pitch equals the matrix row pitch (the headline shape: 208 floats) the 16 rows are one
-    //      contiguous piece in LDS too and go there by LDS-DMA like the weights: no registers, no ds_write, and every
-    //      request of the prologue in flight at once (a ds_write behind an LDS-DMA waits for vmcnt(0)).
+    //      read -- measured -- and it costs a gather, a store and a read of 6.8 MB per step).  The matrix row pitch
+    //      equals the LDS row pitch, so the 16 rows are one contiguous piece in LDS too and go there by LDS-DMA like the
+    //      weights: no registers, no ds_write, and every request of the prologue in flight at once (a ds_write behind an
+    //      LDS-DMA waits for vmcnt(0)).
     constexpr int NLD = (16 * (XP / 4) + 63) / 64;
     const int rp4 = p.RP >> 2, nchunk = 16 * rp4;
     const int row0 = lane / rp4, col0 = lane - row0 * rp4;
 #define LBDRN_LDS_DMA(gptr, lptr) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
                                      (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-    const bool dma_rows = p.RP == XP;
-    if (dma_rows) {
+    {   // (make_train_plan pads the matrix row pitch to the LDS pitch XP: the 16 rows are one lane-linear piece)
         float* dst = Xs + 16 * w * XP;
         if (A.stage_in != nullptr) {
             const float* src = A.stage_in + (size_t)(first + 16 * w) * p.RP + lane * 4;
@@ -1004,46 +1008,6 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
         for (int g = 0; g < G0; ++g) LBDRN_LDS_DMA(src + g * 256, dst + g * 256);
     }
 #undef LBDRN_LDS_DMA
-    // (chunks past the end of the 16 rows -- the last lanes of the last pass -- redo the last chunk: same address,
-    //  same data, and no lane-dependent branch for the compiler to sink the loads into)
-#define LBDRN_ROWS_TO_LDS(v)                                                                                          \
-    {                                                                                                                 \
-        int row = row0, col = col0;                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < NLD; ++u) {                                                             \
-            const bool in = lane + 64 * u < nchunk;                                                                   \
-            *reinterpret_cast<float4*>(Xs + (16 * w + (in ? row : 15)) * XP + 4 * (in ? col : rp4 - 1)) = v[u];       \
-            row += p.w_dp; col += p.w_df;                                                                             \
-            if (col >= rp4) { col -= rp4; row += 1; }                                                                 \
-        }                                                                                                             \
-    }
-    if (!dma_rows) {
-        if (A.stage_in != nullptr) {
-            const float4* src = reinterpret_cast<const float4*>(A.stage_in + (size_t)(first + 16 * w) * p.RP);
-            float4 v[NLD];
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) v[u] = src[min(lane + 64 * u, nchunk - 1)];
-            LBDRN_ROWS_TO_LDS(v)
-        } else {
-            float4 v[NLD];
-            const int pix_mine = clamp_pix(raw_mine);
-            int row = row0, col = col0;
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                const bool in = lane + 64 * u < nchunk;
-                const int pix = __shfl(pix_mine, in ? row : 15);
-                v[u] = *reinterpret_cast<const float4*>(A.rows + (size_t)pix * p.RP + 4 * (in ? col : rp4 - 1));
-                row += p.w_dp; col += p.w_df;
-                if (col >= rp4) { col -= rp4; row += 1; }
-            }
-            LBDRN_ROWS_TO_LDS(v)
-        }
-        const int padc = XP / 4 - rp4;   // columns RP..XP-1: read by layer-0 steps / dW0 strips past the row, must be finite
-        for (int c = lane; c < 16 * padc; c += 64) {
-            const int r = c / padc, cc = c - r * padc;
-            *reinterpret_cast<float4*>(Xs + (16 * w + r) * XP + 4 * (rp4 + cc)) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
-#undef LBDRN_ROWS_TO_LDS
     STAMP(1);
     __syncthreads();   // rows and layer-0 fragments of all four waves are in LDS (drains the LDS-DMA: vmcnt(0))
     STAMP(2);

@@ -28,7 +28,8 @@ def pick(table, kernel_sub, counter):
 
 
 for f in ("kernel_stats_one_in_flight.csv", "kernel_stats_four_in_flight.csv", "pmc_FETCH_SIZE.csv", "pmc_WRITE_SIZE.csv",
-          "sq_a.csv", "sq_b.csv", "bench_one_in_flight.json", "bench_four_in_flight.json"):
+          "sq_a.csv", "sq_b.csv", "bench_one_in_flight.json", "bench_four_in_flight.json", "kernel_stats_bc256.csv",
+          "kernel_stats_embed.csv", "bench_bc256.json", "bench_embed.json"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 fetch, write = load("pmc_FETCH_SIZE.csv"), load("pmc_WRITE_SIZE.csv")

@@ -5,7 +5,7 @@
 #   sq   two SQ counter passes (8 counters each) -> per-kernel means
 # Small CSVs land under gpurun_out/prof_TAG/; the databases are deleted as soon as they are summarised.
 TAG=${1:-r02}; shift
-WHAT=${@:-kt pmc sq}
+WHAT=${@:-kt pmc sq cfg}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -22,6 +22,11 @@ kt)
   summarise $OUT/kt1 $OUT/kernel_stats_one_in_flight.csv scripts/rocprof_kernel_stats.py
   rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
   summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py ;;
+cfg)   # BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING): kernel-trace summaries
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline -bc 256 --in-flight 2 --steps 2 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
+  summarise $OUT/kt_bc256 $OUT/kernel_stats_bc256.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_embed -o run -- python3 bench.py --no-cpu-baseline --coords-embedding --steps 4 > $OUT/bench_embed.json 2> $OUT/kt_embed.err
+  summarise $OUT/kt_embed $OUT/kernel_stats_embed.csv scripts/rocprof_kernel_stats.py ;;
 pmc)
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o run -- $CMDP > /dev/null 2> $OUT/pmc_$C.err; echo "pmc $C rc=$?" >> $OUT/status.txt
