@@ -105,7 +105,11 @@ int lbdrn_decode_fused(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t
 
 /* a9 -- evaluator + LBDRNPerformance (modified_ignite_engine.py:38-43, LBDRNperformance.py:18-21):
  * *sse (device float64) = sum over all pixels and bands of (y - label)^2, fixed summation order
- * (bitwise reproducible).  img is the original [C][H][W] image the labels derive from. */
+ * (bitwise reproducible, on any launch shape).  img is the original [C][H][W] image the labels derive from.
+ * path may carry LBDRN_EVAL_BACKGROUND (path | LBDRN_EVAL_BACKGROUND): the pass is launched on half as many
+ * workgroups, for running on a second stream beside a fit's training steps (which hold the other half of the CUs).
+ * Same *sse bit for bit. */
+#define LBDRN_EVAL_BACKGROUND 0x200
 int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
                    const uint16_t *msb, const float *params, double *sse, void *workspace,
                    size_t workspace_bytes, int32_t path, void *stream);
@@ -115,7 +119,12 @@ int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *im
  * of pixel indices: gather features and labels, forward, MSE loss, backward, Adam update of
  * params/exp_avg/exp_avg_sq in place.  adam_step0 = number of Adam steps already taken;
  * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
- * short (no drop_last, encode.py:69). */
+ * short (no drop_last, encode.py:69).
+ * path of lbdrn_train_epoch may carry LBDRN_STEP_SPREAD (path | LBDRN_STEP_SPREAD): a hint that this fit has the
+ * device to itself -- each step is then cut into twice as many workgroups so that it covers every CU (shorter
+ * steps, more gradient traffic); without it a step takes half of the chip and fits on other streams run beside it.
+ * Same results within the training tolerance either way; shapes without such a kernel ignore the hint. */
+#define LBDRN_STEP_SPREAD 0x100
 size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
 /* Once per image, before the first lbdrn_train_epoch on this workspace: builds the per-image state
  * the fused path keeps in the workspace (the [N][F+C] feature|label row matrix that replaces the

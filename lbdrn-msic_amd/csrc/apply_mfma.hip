@@ -19,6 +19,7 @@
 //    channel-planar LDS (conflict-free for 32 consecutive pixels) with reflect padding applied.
 //  * 8 waves per CU (2 per SIMD): one wave's sin() VALU work overlaps the other's MFMAs.
 #include <atomic>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "lbdrn_math.hpp"
@@ -82,8 +83,8 @@ static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p)
         q.off_rowt = o; o += th * g.P;
         q.off_colt = o; o += TILE_W * g.P;
         q.off_tile = o; o += (g.use_colors ? g.C * q.SH * q.SW : 0);
-        q.lds_floats = o;
-        if ((size_t)o * 4 <= 160 * 1024) break;
+        q.lds_floats = std::max(o, q.off_rowt + 2 * APPLY_THREADS + 4);   // the per-tile regions double as the SSE reduction's doubles
+        if ((size_t)q.lds_floats * 4 <= 160 * 1024) break;
     }
     q.tiles_x = (g.W + TILE_W - 1) / TILE_W;
     q.tiles_y = (g.H + q.TH - 1) / q.TH;
@@ -164,7 +165,9 @@ struct ApplyArgs {
     const uint16_t* img;  // EVAL: original image (labels)
     uint16_t* out;        // DECODE
     float* y_out;         // DECODE, optional
-    double* partial;      // EVAL: [gridDim.x]
+    double* partial;      // EVAL: [nvirt]
+    int nvirt;            // virtual workgroups: virtual workgroup v takes tiles v, v + nvirt, .. and owns partial[v]; a
+                          // launch of fewer real workgroups walks them in turn -- same sums bit for bit on any grid
     unsigned long long* stamps;  // diagnostic build (-DLBDRN_APPLY_STAMPS): [gridDim.x][8] cycle sums of wave 0
 };
 
@@ -241,14 +244,14 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
     const int64_t HW = (int64_t)g.H * g.W;
     const float scale = (float)((1 << g.K) - 1);
     const int lmask = (1 << g.K) - 1;
-    double sse = 0.0;
-
 #ifdef LBDRN_APPLY_STAMPS
     unsigned long long acc_t[8] = {}, last_t;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_t)::"memory");
 #endif
     const int ntiles = p.tiles_x * p.tiles_y;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (int v = blockIdx.x; v < A.nvirt; v += gridDim.x) {
+    double sse = 0.0;
+    for (int t = v; t < ntiles; t += A.nvirt) {
         const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
         const int y0 = ty * p.TH, x0 = tx * TILE_W;
         __syncthreads();  // previous tile fully consumed (and the weight copy landed)
@@ -425,21 +428,22 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             ASTAMP(5);  // epilogue
         }
     }
-#ifdef LBDRN_APPLY_STAMPS
-    if (tid == 0 && A.stamps)
-        for (int k = 0; k < 8; ++k) A.stamps[(size_t)blockIdx.x * 8 + k] = acc_t[k];
-#endif
     if (MODE == MODE_EVAL) {
         __syncthreads();
-        double* red = reinterpret_cast<double*>(lds);  // weights no longer needed
+        double* red = reinterpret_cast<double*>(lds + ((p.off_rowt + 3) & ~3));  // the per-tile regions: consumed
         red[tid] = sse;
         __syncthreads();
         for (int o2 = APPLY_THREADS / 2; o2 > 0; o2 >>= 1) {
             if (tid < o2) red[tid] += red[tid + o2];
             __syncthreads();
         }
-        if (tid == 0) A.partial[blockIdx.x] = red[0];
+        if (tid == 0) A.partial[v] = red[0];
     }
+    }
+#ifdef LBDRN_APPLY_STAMPS
+    if (tid == 0 && A.stamps)
+        for (int k = 0; k < 8; ++k) A.stamps[(size_t)blockIdx.x * 8 + k] = acc_t[k];
+#endif
 }
 
 // one wave: lane l sums partial[l], partial[l + 64], .. in index order, then the 64 lane sums pairwise in a fixed tree
@@ -476,7 +480,7 @@ static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s)
 
 static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const uint16_t* img,
                      const uint16_t* msb, const float* params, uint16_t* out, float* y_out,
-                     double* sse, void* ws, size_t ws_bytes, hipStream_t s)
+                     double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
 {
     ApplyArgs A;
     if (!make_plan(g, net, &A.p)) {
@@ -502,7 +506,10 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    int grid = std::min(std::min(A.p.tiles_x * A.p.tiles_y, cus), MFMA_PARTIALS);
+    A.nvirt = std::min(std::min(A.p.tiles_x * A.p.tiles_y, cus), MFMA_PARTIALS);
+    // a background pass (beside a training stream that holds the other half of the CUs) launches half as many
+    // workgroups, each walking two virtual ones
+    const int grid = background ? std::max(1, A.nvirt / 2) : A.nvirt;   // (a quarter / a sixth: 3 / 10 ms per tile slower)
     int rc;
     if (mode == MODE_DECODE) {
         rc = A.p.NT == 1 ? launch_apply<1, MODE_DECODE>(A, grid, s)
@@ -513,7 +520,7 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
            : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s)
                          : launch_apply<4, MODE_EVAL>(A, grid, s);
         if (rc) return rc;
-        k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, grid, sse);
+        k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, A.nvirt, sse);
         LBDRN_LAUNCH_CHECK();
     }
 #ifdef LBDRN_APPLY_STAMPS
@@ -534,14 +541,14 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
 int mfma_decode(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* msb, const float* params,
                 uint16_t* out, float* y_out, void* ws, size_t ws_bytes, hipStream_t s)
 {
-    return run_apply(g, net, MODE_DECODE, nullptr, msb, params, out, y_out, nullptr, ws, ws_bytes, s);
+    return run_apply(g, net, MODE_DECODE, nullptr, msb, params, out, y_out, nullptr, ws, ws_bytes, false, s);
 }
 
 int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                   const uint16_t* msb, const float* params, double* sse, void* ws, size_t ws_bytes,
-                  hipStream_t s)
+                  bool background, hipStream_t s)
 {
-    return run_apply(g, net, MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes, s);
+    return run_apply(g, net, MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes, background, s);
 }
 
 }  // namespace lbdrn

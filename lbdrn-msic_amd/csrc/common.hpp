@@ -87,6 +87,6 @@ int mfma_decode(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* msb, 
                 uint16_t* out, float* y_out, void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                   const uint16_t* msb, const float* params, double* sse, void* ws, size_t ws_bytes,
-                  hipStream_t s);
+                  bool background, hipStream_t s);
 
 }  // namespace lbdrn

@@ -4,6 +4,7 @@ fit_image() stands where the reference's encode.train() stands (ref encode.py:67
 apply_image() where decode.test()'s numeric core stands (ref decode.py:73-134); file handling,
 payload coding and logging stay in encode.py / decode.py.
 """
+import os
 import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -90,10 +91,20 @@ class DeviceFit:
 _RNG_LOCK = threading.Lock()   # the global torch CPU generator is one per process
 _POOL_LOCK = threading.Lock()
 _FIT_STREAMS = {}               # device -> streams the fits in flight run on
+_EVAL_STREAMS = {}              # (device, stream a fit runs on) -> the stream its evaluation passes run on
+
+
+def _eval_stream(dev, main):
+    """One evaluation stream per stream a fit runs on, kept for the life of the process (like _FIT_STREAMS)."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
+    with _POOL_LOCK:
+        if key not in _EVAL_STREAMS:
+            _EVAL_STREAMS[key] = torch.cuda.Stream(device=dev)
+        return _EVAL_STREAMS[key]
 
 
 def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1,
-               cfg=None, path=ops.PATH_AUTO, keep_losses=False, seed=None, draws=None):
+               cfg=None, path=ops.PATH_AUTO, keep_losses=False, seed=None, draws=None, alone=True):
     """Fit one image that already sits in HBM (img_d: [C,H,W] uint16 bits in int16 storage), on the
     calling thread's current stream.
 
@@ -102,7 +113,8 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     iterator per train / eval pass (lbdrn_hip.sampler).  With `seed`, the fit seeds the generator
     itself and makes all its draws in one critical section, so that fits running on several
     threads (fit_many) each see what a freshly seeded process would; with `draws` (draw_fit) the generator
-    is not touched at all.  No host synchronisation
+    is not touched at all.  `alone`: this fit has the device to itself (no other fit in flight) -- its
+    evaluation passes then run in the background of the next epoch's training (below).  No host synchronisation
     happens inside except the scalar read of MSB.max() that sizes the normalisation
     (ref LBDRNdataset.py:120)."""
     cfg = cfg or FeatCfg.from_constants()
@@ -128,6 +140,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     params = draws.params.to(dev).contiguous()
     if params.numel() != ops.param_count(net):
         raise ValueError("draws were made for another network shape")
+    draws_params0 = params.clone()
     exp_avg = torch.zeros_like(params)
     exp_avg_sq = torch.zeros_like(params)
     lrs = lr_schedule(lr, epochs)
@@ -135,26 +148,48 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     losses = torch.zeros((epochs, steps_per_epoch), dtype=torch.float32, device=dev) if keep_losses else None
     train_ws = ops.TrainWorkspace(geom, net, batch_size, dev).prepare(img_d, msb_d, path)   # a2-a4
     apply_ws = ops.ApplyWorkspace(geom, net, dev)
-    best_params = params.clone()
-    best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)   # encode.py:91
     mse_log = torch.zeros((epochs, 2), dtype=torch.float32, device=dev)
+    eval_epochs = [] if epochs == 1 else [e for e in range(1, epochs + 1) if e % min(val_duration, epochs) == 0]
+    # A fit alone on the device: its train steps are a chain of short kernels on half of the CUs, so the evaluation
+    # pass of epoch e (a9) reads a snapshot of the weights on a second stream, launched on half as many workgroups
+    # (EVAL_BACKGROUND: same sum bit for bit), while epoch e+1 trains on the other half -- instead of standing in
+    # the chain.  With other fits in flight the chip is full anyway and a whole-chip pass in the chain is faster
+    # (measured).  Which epoch was best is settled after the last pass: same rule, same order.
+    main = torch.cuda.current_stream(dev)
+    if os.environ.get("LBDRN_OVERLAP_EVAL") in ("0", "1"):   # A/B measurements
+        alone = os.environ["LBDRN_OVERLAP_EVAL"] == "1"
+    side = _eval_stream(dev, main) if alone and eval_epochs else None
+    snaps = torch.empty((max(len(eval_epochs), 1), params.numel()), dtype=torch.float32, device=dev)
+    mses = torch.zeros((max(len(eval_epochs), 1),), dtype=torch.float32, device=dev)
+    if side is not None:
+        side.wait_stream(main)       # the workspaces and the planes above are ready
     adam_steps = 0
     for e in range(1, epochs + 1):
         perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
         ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
                         adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
         adam_steps += steps_per_epoch
-        if epochs == 1:                                                   # encode.py:100-103
-            best_params.copy_(params)
-        elif e % min(val_duration, epochs) == 0:                          # encode.py:104-117
-            sse = ops.eval_sse(geom, net, img_d, msb_d, params, path, apply_ws)   # a9
-            mse = (sse / float(N * C)).float()
-            improved = mse < best_mse
-            best_params = torch.where(improved, params, best_params)
-            best_mse = torch.where(improved, mse, best_mse)
-            mse_log[e - 1, 0] = mse[0]
-            mse_log[e - 1, 1] = improved[0].float()
+        if e in eval_epochs:                                              # encode.py:104-117
+            k = eval_epochs.index(e)
+            snaps[k].copy_(params)
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                background = side is not None and e != epochs      # nothing trains beside the last pass
+                sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background)   # a9
+                mses[k:k + 1].copy_((sse / float(N * C)).float())
             out.evaluated.append(e)
+    if side is not None:
+        main.wait_stream(side)
+    best_params = params.clone() if epochs == 1 else draws_params0      # encode.py:100-103 / :91
+    best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)   # encode.py:91
+    for k, e in enumerate(eval_epochs):
+        mse = mses[k:k + 1]
+        improved = mse < best_mse
+        best_params = torch.where(improved, snaps[k], best_params)
+        best_mse = torch.where(improved, mse, best_mse)
+        mse_log[e - 1, 0] = mse[0]
+        mse_log[e - 1, 1] = improved[0].float()
     stream.close()
     out.best_params, out.msb, out.msb_max, out.geom, out.net = best_params, msb_d, msb_max, geom, net
     out.mse_log, out.losses, out.epochs = mse_log, losses, epochs
@@ -202,7 +237,7 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
             local.stream.wait_stream(caller)
         with torch.cuda.stream(local.stream):
             fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
-                             path, seed=seed, draws=dr)
+                             path, seed=seed, draws=dr, alone=False)
             out = then(fit) if then is not None else fit
             done = torch.cuda.Event()
             done.record(local.stream)

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Geom, Net, PATH_AUTO, check, lib
+from ._lib import EVAL_BACKGROUND, Geom, Net, PATH_AUTO, STEP_SPREAD, check, lib
 
 
 def _call(fn, ref, *args):
@@ -140,8 +140,9 @@ def decode_fused(geom, net, msb, params, want_y=False, path=PATH_AUTO, ws=None):
     return (out, y) if want_y else out
 
 
-def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None):
-    """Whole-image sum of squared error as a device float64 scalar tensor (no sync)."""
+def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None, background=False):
+    """Whole-image sum of squared error as a device float64 scalar tensor (no sync).
+    background: launch on half as many workgroups (LBDRN_EVAL_BACKGROUND, lbdrn_hip.h); same sum bit for bit."""
     _need_cuda(img, msb, params)
     img = _u16(img.contiguous())
     msb = _u16(msb.contiguous())
@@ -149,7 +150,8 @@ def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None):
     sse = out if out is not None else torch.zeros(1, dtype=torch.float64, device=msb.device)
     ws = ws or ApplyWorkspace(geom, net, msb.device)
     _call(lib().lbdrn_eval_sse, msb, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
-                               _ptr(params), _ptr(sse), _ptr(ws.buf), ws.nbytes, path)
+                               _ptr(params), _ptr(sse), _ptr(ws.buf), ws.nbytes,
+                               path | (EVAL_BACKGROUND if background else 0))
     return sse
 
 
@@ -171,8 +173,9 @@ class TrainWorkspace:
 
 
 def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_sq, adam_step0, lr,
-                losses=None, path=PATH_AUTO, ws=None):
-    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor."""
+                losses=None, path=PATH_AUTO, ws=None, spread=False):
+    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor.
+    spread: the fit has the device to itself -- each step covers every CU (LBDRN_STEP_SPREAD, lbdrn_hip.h)."""
     _need_cuda(img, msb, perm, params, exp_avg, exp_avg_sq, losses)
     img = _u16(img.contiguous())
     msb = _u16(msb.contiguous())
@@ -186,7 +189,7 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
     _call(lib().lbdrn_train_epoch, img, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
                                   _ptr(perm), perm.numel(), batch_size, _ptr(params), _ptr(exp_avg),
                                   _ptr(exp_avg_sq), adam_step0, float(lr), _ptr(losses), _ptr(ws.buf),
-                                  ws.nbytes, path)
+                                  ws.nbytes, path | (STEP_SPREAD if spread else 0))
 
 
 def train_profile_mode(mode):
