@@ -119,12 +119,7 @@ int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *im
  * of pixel indices: gather features and labels, forward, MSE loss, backward, Adam update of
  * params/exp_avg/exp_avg_sq in place.  adam_step0 = number of Adam steps already taken;
  * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
- * short (no drop_last, encode.py:69).
- * path of lbdrn_train_epoch may carry LBDRN_STEP_SPREAD (path | LBDRN_STEP_SPREAD): a hint that this fit has the
- * device to itself -- each step is then cut into twice as many workgroups so that it covers every CU (shorter
- * steps, more gradient traffic); without it a step takes half of the chip and fits on other streams run beside it.
- * Same results within the training tolerance either way; shapes without such a kernel ignore the hint. */
-#define LBDRN_STEP_SPREAD 0x100
+ * short (no drop_last, encode.py:69). */
 size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
 /* Once per image, before the first lbdrn_train_epoch on this workspace: builds the per-image state
  * the fused path keeps in the workspace (the [N][F+C] feature|label row matrix that replaces the

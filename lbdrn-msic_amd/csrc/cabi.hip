@@ -13,7 +13,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
 int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
-                     size_t ws_bytes, bool spread, hipStream_t s);
+                     size_t ws_bytes, hipStream_t s);
 int train_profile_mode(int mode);
 size_t randperm_workspace(int64_t n, int count);
 size_t plane_bound(int C, int H, int W);
@@ -227,8 +227,6 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
     LBDRN_REQUIRE(img && msb && perm && params && exp_avg && exp_avg_sq, "null pointer");
     LBDRN_REQUIRE(n >= 0 && batch_size >= 1 && adam_step0 >= 0, "bad n/batch_size/adam_step0");
     NEED_DEVICE();
-    const bool spread = (path & LBDRN_STEP_SPREAD) != 0;
-    path &= ~LBDRN_STEP_SPREAD;
     const bool ok = mfma_train_supported(*g, *net);
     if (path == LBDRN_PATH_MFMA && !ok) {
         set_error("fused MFMA train kernel does not support this shape");
@@ -237,7 +235,7 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
     LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
     if (ok && path != LBDRN_PATH_GENERIC)
         return mfma_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
-                                adam_step0, lr, losses, workspace, workspace_bytes, spread, (hipStream_t)stream);
+                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
     return generic_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
 }

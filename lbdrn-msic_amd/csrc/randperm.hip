@@ -11,8 +11,8 @@
 // j_i = i + z_i just before step i.  That value is p itself if no earlier step targeted p, else it is
 // whatever sat at position i' before step i', where i' is the latest step < i with j_i' = p -- a
 // chain that walks to ever earlier steps (one hop on average).  So:
-//   1. one workgroup runs the MT19937 recurrence (three 227-wide phases per 624 words) and emits the
-//      targets j_i;  2. the steps are bucketed by target (count, exclusive scan, scatter);
+//   1. one wave runs the MT19937 recurrence and emits the raw words; the targets j_i are made of them by
+//      4 M threads;  2. the steps are bucketed by target (count, exclusive scan, scatter);
 //   3. every position chases its chain through the buckets, independently.
 // Bucket order is irrelevant (each hop takes the maximum step below a bound), so the atomics used to
 // fill the buckets do not affect the result.  tests/test_gpu_randperm.py checks equality with
@@ -41,51 +41,77 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
     return y;
 }
 
-// j[i] = i + mt19937_output(i) % (n - i) for i < n-1;  j[n-1] = n-1.  One workgroup of 256 threads per
-// permutation (blockIdx.x): the recurrence is serial (5 ms for 4 M words), so the permutations of all
-// epochs of a fit are generated side by side in one launch.
+// raw[i] = word i of the mt19937 state sequence (untempered) for i < n-1, one permutation per workgroup.
+// The recurrence x[k+624] = x[k+397] ^ twist(x[k], x[k+1]) is serial at a distance of 227 words, so a permutation is
+// ONE wave walking the state in ten 64-word chunks, with no barrier anywhere (4.19 M words: 5.5 ms as a 256-thread
+// workgroup with four barriers per 624 words -- the first thing a fit waits for -- against 3 ms here):
+//  * a lane keeps "its" ten state words in registers from block to block (word 64c + lane of chunk c);
+//  * x[k+1] and x[k+397] / the already renewed x[k-227] come from an LDS copy of the state, written as each chunk is
+//    renewed and read three chunks ahead of their use (LDS operations of one wave complete in order; a DPP wave shift
+//    for x[k+1] costs more issue slots than the read).
+// Tempering and the "% (n - i)" are left to the first consumer, which has 4 M threads to do them with.
 struct SeedList { uint32_t s[32]; };
-__global__ void __launch_bounds__(256) k_mt19937_targets(SeedList seeds, uint32_t n, uint32_t* __restrict__ jall, size_t jstride)
+__global__ void __launch_bounds__(64) k_mt19937_raw(SeedList seeds, uint32_t n, uint32_t* __restrict__ jall, size_t jstride)
 {
-    __shared__ uint32_t st[2][MT_N];
-    const int tid = threadIdx.x;
-    const uint32_t seed = seeds.s[blockIdx.x];
-    uint32_t* __restrict__ j = jall + (size_t)blockIdx.x * jstride;
-    if (tid == 0) {  // init_genrand, as at::mt19937(seed)
-        uint32_t x = seed;
-        st[0][0] = x;
+    __shared__ uint32_t st[MT_N + 16];
+    const int lane = threadIdx.x;
+    uint32_t* __restrict__ raw = jall + (size_t)blockIdx.x * jstride;
+    if (lane == 0) {  // init_genrand, as at::mt19937(seed)
+        uint32_t x = seeds.s[blockIdx.x];
+        st[0] = x;
         for (int k = 1; k < MT_N; ++k) {
             x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
-            st[0][k] = x;
+            st[k] = x;
         }
-        if (n > 0) j[n - 1] = n - 1;
+        if (n > 0) raw[n - 1] = n - 1;   // (position n-1 is its own target; the consumers leave it alone)
     }
     __syncthreads();
     const uint32_t steps = n > 0 ? n - 1 : 0;
-    int cur = 0;
-    for (uint32_t base = 0; base < steps; base += MT_N) {
-        const uint32_t* o = st[cur];
-        uint32_t* w = st[cur ^ 1];
-        if (tid < 227) w[tid] = o[tid + MT_M] ^ mt_twist(o[tid], o[tid + 1]);
-        __syncthreads();
-        if (tid < 227) w[tid + 227] = w[tid] ^ mt_twist(o[tid + 227], o[tid + 228]);
-        __syncthreads();
-        if (tid < 169) w[tid + 454] = w[tid + 227] ^ mt_twist(o[tid + 454], o[tid + 455]);
-        if (tid == 169) w[623] = w[396] ^ mt_twist(o[623], w[0]);
-        __syncthreads();
-        for (int k = tid; k < MT_N; k += 256) {
-            const uint32_t i = base + k;
-            if (i < steps) j[i] = i + mt_temper(w[k]) % (n - i);
-        }
-        cur ^= 1;  // the next block reads this one (the barrier above orders the writes before those reads,
-                   // and the outputs read w, which the next block only reads as well)
+    constexpr int NC = 10;   // chunks: words 64c + lane, the last one 48 wide
+    uint32_t a[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a[c] = (64 * c + lane) < MT_N ? st[64 * c + lane] : 0u;
+    int midx[NC], bidx[NC];  // where chunk c finds x[k+397] (not renewed yet) or the renewed x[k-227]; and x[k+1]
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int k = 64 * c + lane;
+        midx[c] = k + MT_M < MT_N ? k + MT_M : (k < MT_N ? k - (MT_N - MT_M) : 0);
+        bidx[c] = k + 1 < MT_N ? k + 1 : 0;   // x[k+1]; word 623 takes the renewed word 0
     }
+    auto block = [&](uint32_t base, bool whole) {   // renew the 624 words, store those below `steps`
+        uint32_t m[NC], b[NC];
+        uint32_t* __restrict__ dst = raw + base + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { m[c] = st[midx[c]]; b[c] = st[64 * c + lane + 1]; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const uint32_t y = (a[c] & 0x80000000u) | (b[c] & 0x7fffffffu);
+            const uint32_t v = m[c] ^ (y >> 1) ^ ((b[c] & 1u) ? 0x9908b0dfu : 0u);
+            a[c] = v;
+            const int k = 64 * c + lane;
+            if (c < NC - 1 || k < MT_N) {
+                st[k] = v;
+                if (whole || base + (uint32_t)k < steps) dst[64 * c] = v;
+            }
+            if (c + 3 < NC) { m[c + 3] = st[midx[c + 3]]; b[c + 3] = st[bidx[c + 3]]; }
+        }
+    };
+    uint32_t base = 0;
+    for (; base + MT_N <= steps; base += MT_N) block(base, true);
+    if (base < steps) block(base, false);
 }
 
-__global__ void __launch_bounds__(256) k_count_targets(const uint32_t* __restrict__ j, uint32_t steps, uint32_t* __restrict__ cnt)
+__device__ __forceinline__ uint32_t mt_target(uint32_t raw, uint32_t i, uint32_t n) { return i + mt_temper(raw) % (n - i); }
+
+// j[i] = i + mt19937_output(i) % (n - i) for i < n-1, in place over the raw words; and the bucket sizes
+__global__ void __launch_bounds__(256) k_count_targets(uint32_t* __restrict__ j, uint32_t steps, uint32_t n, uint32_t* __restrict__ cnt)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < steps) atomicAdd(&cnt[j[i]], 1u);
+    if (i < steps) {
+        const uint32_t t = mt_target(j[i], i, n);
+        j[i] = t;
+        atomicAdd(&cnt[t], 1u);
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -172,13 +198,13 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
     const uint32_t un = (uint32_t)n, steps = un - 1;
     SeedList sl;
     for (int c = 0; c < 32; ++c) sl.s[c] = c < count ? (uint32_t)(seeds[c] & 0xffffffffu) : 0u;
-    k_mt19937_targets<<<count, 256, 0, s>>>(sl, un, w.j, w.arr / sizeof(uint32_t));
+    k_mt19937_raw<<<count, 64, 0, s>>>(sl, un, w.j, w.arr / sizeof(uint32_t));
     LBDRN_LAUNCH_CHECK();
     for (int c = 0; c < count; ++c) {
-        const uint32_t* j = w.j + (size_t)c * (w.arr / sizeof(uint32_t));
+        uint32_t* j = w.j + (size_t)c * (w.arr / sizeof(uint32_t));
         LBDRN_HIP_TRY(hipMemsetAsync(w.cnt, 0, 2 * w.arr, s));
         if (steps) {
-            k_count_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, w.cnt);
+            k_count_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, un, w.cnt);
             LBDRN_LAUNCH_CHECK();
         }
         LBDRN_HIP_TRY(rocprim::exclusive_scan(w.scan_tmp, w.scan_bytes, w.cnt, w.off, 0u, (size_t)n,

@@ -93,8 +93,6 @@ struct TrainPlan {
     int pk_wht, pk_wlt;        // wave-local kernel: W_l^T and W_last^T fragments for the backward products
     int w_dp, w_df;            // 64 / (RP/4) and 64 % (RP/4): chunk walk of the row copy
     int wave_lds_floats;
-    int pair;                  // 1: a step runs as 256 workgroups of 32 samples (k_train_pair: one fit alone on the device)
-    int pair_lds_floats;
     int sl_hid, sl_out, sl_bias, slab_floats;  // slab (tile order) section starts, in floats
     int lds_x, lds_xt, lds_h, lds_ht, lds_z, lds_zt, lds_zo, lds_zot, lds_pix, lds_red, lds_floats;
 };
@@ -137,8 +135,6 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
         // pitch (a wave's 16 rows are then one lane-linear piece): the row matrix is padded to it (config 1: 208 = 208;
         // positional embedding, F = 250: 260 -> 272 floats, 4.6 % more rows traffic for a prologue without registers)
         if (p.wave) p.RP = xp;
-        p.pair_lds_floats = 32 * xp + std::max(p.LQ * 256, net.nl * 32 * WHP + net.nl * TBC_W * 36 + 32 * WOP + 36);
-        p.pair = 0;   // chosen per call (mfma_train_epoch's spread argument); the shapes are those of the wave-local kernel
         const int rp4 = p.RP / 4;
         p.w_dp = 64 / rp4;
         p.w_df = 64 % rp4;
@@ -1350,7 +1346,6 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #endif
 }
 
-#include "train_pair.inc"
 #include "train_wide.inc"
 
 static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net)
@@ -1434,48 +1429,8 @@ static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
     }
 }
 
-template <int LQ, int NL>
-static int launch_pair(const TrainArgs& A, int nwg, hipStream_t s)
-{
-    static_assert(pair_lds_total(LQ, NL) * 4 <= 160 * 1024, "LDS");
-    auto kern = k_train_pair<LQ, NL>;
-    kern<<<nwg, WAVE_THREADS, (size_t)A.p.pair_lds_floats * 4, s>>>(A);
-    LBDRN_LAUNCH_CHECK();
-    return 0;
-}
-
-template <int LQ, int NL>
-static int configure_pair(const TrainPlan& p)
-{
-    LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_pair<LQ, NL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p.pair_lds_floats * 4));
-    return 0;
-}
-
-static int configure_pair_kernel(const TrainPlan& p, int nl)
-{
-    switch (p.LQ) {
-        case 16: return nl == 1 ? configure_pair<16, 1>(p) : configure_pair<16, 2>(p);
-        case 32: return nl == 1 ? configure_pair<32, 1>(p) : configure_pair<32, 2>(p);
-        case 52: return nl == 1 ? configure_pair<52, 1>(p) : configure_pair<52, 2>(p);
-        default: return nl == 1 ? configure_pair<64, 1>(p) : configure_pair<64, 2>(p);
-    }
-}
-
-static int dispatch_pair(const TrainArgs& A, int nwg, hipStream_t s)
-{
-    const bool one = A.net.nl == 1;
-    switch (A.p.LQ) {
-        case 16: return one ? launch_pair<16, 1>(A, nwg, s) : launch_pair<16, 2>(A, nwg, s);
-        case 32: return one ? launch_pair<32, 1>(A, nwg, s) : launch_pair<32, 2>(A, nwg, s);
-        case 52: return one ? launch_pair<52, 1>(A, nwg, s) : launch_pair<52, 2>(A, nwg, s);
-        default: return one ? launch_pair<64, 1>(A, nwg, s) : launch_pair<64, 2>(A, nwg, s);
-    }
-}
-
 static int dispatch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
-    if (A.p.pair) return dispatch_pair(A, nwg, s);
     if (A.p.wave) return dispatch_wave(A, nwg, s);
     switch (A.p.LQ) {
         case 16: return dispatch_nl<16>(A, nwg, s);
@@ -1535,7 +1490,7 @@ int train_profile_mode(int mode)
 int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
-                     size_t ws_bytes, bool spread, hipStream_t s)
+                     size_t ws_bytes, hipStream_t s)
 {
     TrainArgs A;
     if (!make_train_plan(g, net, &A.p))
@@ -1563,15 +1518,9 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
     const int max_wg = (bs + TB - 1) / TB;
     LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 8 * 16 * sizeof(unsigned long long)));
 #endif
-    {
-        const char* force = getenv("LBDRN_TRAIN_KERNEL");   // "pair" / "wave": A/B measurements
-        A.p.pair = A.p.wave && (force ? force[0] == 'p' : spread) && (size_t)A.p.pair_lds_floats * 4 <= 160 * 1024;
-    }
-    if (A.p.pair) {
-        if (int rc = configure_pair_kernel(A.p, net.nl)) return rc;
-    } else if (A.p.wave)
+    if (A.p.wave)
         if (int rc = configure_wave_kernel(A.p, net.nl)) return rc;
-    const int rows_per_wg = A.p.pair ? PB : A.p.wave ? WB : TB;
+    const int rows_per_wg = A.p.wave ? WB : TB;
     int64_t step = step0;
     int si = 0;
     for (int64_t first = 0; first < n; first += bs, ++si) {
@@ -1614,11 +1563,11 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
             t0min = std::min(t0min, h[k * 16 + 14]);
             t1max = std::max(t1max, h[k * 16 + 15]);
         }
-        fprintf(stderr, "[lbdrn stamps, %s] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
+        fprintf(stderr, "[lbdrn stamps, wave kernel] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
                         "mean cycles: W0 DMA + rows->LDS %.0f | barrier 1 %.0f | small-matrix requests + layer0 %.0f | barrier 2 %.0f | "
                         "act0 %.0f | hidden+act %.0f | out+loss %.0f | backward %.0f | barrier 3 %.0f | dW0 strips %.0f | dW tail+hidden %.0f | "
                         "bias sums %.0f | drain %.0f\n",
-                A.p.pair ? "pair kernel (barrier 2 = act0, act0 = exchange)" : "wave kernel", clk / nw, span / nw, (double)(t1max - t0min) / 100.0, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw, d[5] / nw, d[6] / nw,
+                clk / nw, span / nw, (double)(t1max - t0min) / 100.0, d[1] / nw, d[2] / nw, d[3] / nw, d[4] / nw, d[5] / nw, d[6] / nw,
                 d[7] / nw, d[8] / nw, d[9] / nw, d[10] / nw, d[11] / nw, d[12] / nw, d[13] / nw);
     } else {   // diagnostic: mean cycles per phase over the workgroups of the last step
         LBDRN_HIP_TRY(hipStreamSynchronize(s));

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("LBDRN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "liblbdrn_hip.so")
 
 PATH_AUTO, PATH_GENERIC, PATH_MFMA = 0, 1, 2
-STEP_SPREAD, EVAL_BACKGROUND = 0x100, 0x200   # hints OR'ed into `path` of lbdrn_train_epoch / lbdrn_eval_sse
+EVAL_BACKGROUND = 0x200   # hint OR'ed into `path` of lbdrn_eval_sse
 
 
 class LbdrnError(RuntimeError):

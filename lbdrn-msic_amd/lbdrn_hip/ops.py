@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EVAL_BACKGROUND, Geom, Net, PATH_AUTO, STEP_SPREAD, check, lib
+from ._lib import EVAL_BACKGROUND, Geom, Net, PATH_AUTO, check, lib
 
 
 def _call(fn, ref, *args):
@@ -173,9 +173,8 @@ class TrainWorkspace:
 
 
 def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_sq, adam_step0, lr,
-                losses=None, path=PATH_AUTO, ws=None, spread=False):
-    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor.
-    spread: the fit has the device to itself -- each step covers every CU (LBDRN_STEP_SPREAD, lbdrn_hip.h)."""
+                losses=None, path=PATH_AUTO, ws=None):
+    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor."""
     _need_cuda(img, msb, perm, params, exp_avg, exp_avg_sq, losses)
     img = _u16(img.contiguous())
     msb = _u16(msb.contiguous())
@@ -189,7 +188,7 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
     _call(lib().lbdrn_train_epoch, img, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
                                   _ptr(perm), perm.numel(), batch_size, _ptr(params), _ptr(exp_avg),
                                   _ptr(exp_avg_sq), adam_step0, float(lr), _ptr(losses), _ptr(ws.buf),
-                                  ws.nbytes, path | (STEP_SPREAD if spread else 0))
+                                  ws.nbytes, path)
 
 
 def train_profile_mode(mode):

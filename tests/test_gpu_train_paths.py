@@ -289,6 +289,9 @@ def test_full_size_properties(dev):
     s1 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA).item())
     s2 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item())
     assert abs(s1 - s2) <= 1e-12 * s2
+    # a background pass (half as many workgroups, each walking two virtual ones) gives the same double, bit for bit
+    s3 = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA, background=True)
+    assert float(s3.item()) == s1
     # SSE is consistent with the decoded raster: sum((y - lab)^2) vs residuals, within rounding of y*31
     lsb_err = ((rec & 31).astype(np.float64) - (img & 31)) / 31.0
     assert abs(np.sum(lsb_err ** 2) - s1) / s1 < 0.05
@@ -357,6 +360,31 @@ def test_large_tile_64bit_indexing(dev):
     assert torch.equal(a, b)
     rec = ops.from_device_u16(a[:, -64:, :])
     assert np.array_equal(rec >> K, img[:, -64:, :] >> K)
+
+
+@pytest.mark.parametrize("shape", [(8, 48, 64), (3, 17, 200), (4, 130, 70), (1, 9, 9)])
+def test_background_evaluation_pass_is_the_same_sum(dev, shape):
+    """LBDRN_EVAL_BACKGROUND: any launch shape, the same float64 -- small rasters with fewer tiles than CUs, ragged
+    tiles, a single tile; and a whole fit whose passes ran beside its training equals one whose passes stood in the chain."""
+    C, H, W = shape
+    img = synthetic_tile(7 + C, C, H, W)
+    img_d = ops.to_device_u16(img, dev)
+    msb_d, mx = ops.split_bits(img_d, 5)
+    geom = ops.FeatureGeometry(C, H, W, 5, 2, mx, FeatCfg(), dev)
+    F = FeatCfg().feature_dim(C, 2)
+    net = ops.make_net(F, 64, C, 2)
+    p = torch.from_numpy(_params(np.random.default_rng(C), F, 64, C, 2) * 2.0).to(dev)
+    a = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA)
+    b = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA, background=True)
+    c = ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN, background=True)   # the generic path ignores the hint
+    assert a.item() == b.item() and a.item() > 0
+    assert abs(c.item() - a.item()) <= 1e-11 * a.item()
+    fits = []
+    for alone in (True, False):
+        torch.manual_seed(19920517)
+        fits.append(codec.fit_device(img_d, 5, 2, 64, 2, 1e-3, 256, 3, alone=alone))
+    assert torch.equal(fits[0].best_params.view(torch.int32), fits[1].best_params.view(torch.int32))
+    assert torch.equal(fits[0].mse_log, fits[1].mse_log)
 
 
 def test_fits_in_flight_together_equal_fits_one_by_one(dev):

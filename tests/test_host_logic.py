@@ -19,6 +19,11 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), name
     assert _lib.lib().lbdrn_abi_version() == 1
+    # the constants the Python host mirrors
+    consts = {k: int(v, 0) for k, v in re.findall(r"#define (LBDRN_[A-Z_]+) (0x[0-9a-fA-F]+|\d+)\b", hdr)}
+    assert (consts["LBDRN_PATH_AUTO"], consts["LBDRN_PATH_GENERIC"], consts["LBDRN_PATH_MFMA"]) == \
+        (_lib.PATH_AUTO, _lib.PATH_GENERIC, _lib.PATH_MFMA)
+    assert consts["LBDRN_EVAL_BACKGROUND"] == _lib.EVAL_BACKGROUND and _lib.EVAL_BACKGROUND > _lib.PATH_MFMA
 
 
 def test_geometry_helpers_without_device():
