@@ -896,6 +896,25 @@ __device__ __forceinline__ float train_sigmoid(float z)
     return z >= 0.0f ? r : e * r;
 }
 
+// sin and cos of the training step (a tolerance contract like the sigmoid above; the decode / evaluation kernels keep
+// the canonical polynomial sin of lbdrn_math.hpp): the hardware's v_sin_f32 / v_cos_f32 -- arguments in revolutions,
+// quarter rate -- behind a compensated reduction: x / (2 pi) as a float32 product, plus that product's exact residual
+// and x times the low half of 1 / (2 pi).  4.5e-7 absolute over the range the activations see (scripts/sin_probe.hip:
+// the intrinsic error of the instructions), five full-rate and two quarter-rate instructions against canon_sincos's 31.
+#ifdef LBDRN_TRAIN_CANON_SINCOS
+__device__ __forceinline__ void train_sincos(float x, float& sn, float& cs) { canon_sincos(x, sn, cs); }
+#else
+__device__ __forceinline__ void train_sincos(float x, float& sn, float& cs)
+{
+    constexpr float kHi = 0x1.45f306p-3f, kLo = 0x1.b93910p-28f;   // 1 / (2 pi) = kHi + kLo
+    const float rev = x * kHi;
+    const float res = __builtin_fmaf(x, kHi, -rev);                 // exact
+    const float f = __builtin_amdgcn_fractf(rev) + __builtin_fmaf(x, kLo, res);
+    sn = __builtin_amdgcn_sinf(f);
+    cs = __builtin_amdgcn_cosf(f);
+}
+#endif
+
 // sum over the 64 lanes, same order every time, no LDS: rows of 16 by DPP shifts, then the four row totals
 // sum over each row of 16 lanes (DPP shifts, zero fill): lane 15 of a row holds the row's total
 __device__ __forceinline__ float row_sum16(float x)
@@ -1092,7 +1111,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float sn, co;
-                canon_sincos(30.0f * acc[t][r], sn, co);
+                train_sincos(30.0f * acc[t][r], sn, co);
                 h[t][r] = sn;
                 cs[l][t][r] = co;
             }
