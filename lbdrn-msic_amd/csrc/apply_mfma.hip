@@ -92,10 +92,14 @@ static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p)
     return true;
 }
 
+struct WApplyPlan;
+static bool wapply_supported(const lbdrn_geom& g, const lbdrn_net& net);
+static size_t wapply_workspace(const lbdrn_geom& g, const lbdrn_net& net);
+
 bool mfma_apply_supported(const lbdrn_geom& g, const lbdrn_net& net)
 {
     ApplyPlan p;
-    return make_plan(g, net, &p);
+    return make_plan(g, net, &p) || wapply_supported(g, net);
 }
 
 constexpr int MFMA_PARTIALS = 1024;
@@ -103,7 +107,7 @@ constexpr int MFMA_PARTIALS = 1024;
 size_t mfma_apply_workspace(const lbdrn_geom& g, const lbdrn_net& net)
 {
     ApplyPlan p;
-    if (!make_plan(g, net, &p)) return 0;
+    if (!make_plan(g, net, &p)) return wapply_workspace(g, net);
     return align_up((size_t)p.pack_floats * 4, 256) + align_up(MFMA_PARTIALS * sizeof(double), 256);
 }
 
@@ -478,15 +482,96 @@ static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s)
     return 0;
 }
 
+#include "apply_wide.inc"
+
+static bool wapply_supported(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    WApplyPlan p;
+    return make_wapply_plan(g, net, &p);
+}
+static size_t wapply_workspace(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    WApplyPlan p;
+    if (!make_wapply_plan(g, net, &p)) return 0;
+    return align_up((size_t)p.pack_floats * 4, 256) + align_up(MFMA_PARTIALS * sizeof(double), 256);
+}
+
+template <int NT, int NL, int MODE>
+static int launch_wapply(const WApplyArgs& A, int grid, hipStream_t s)
+{
+    k_apply_wide<NT, NL, MODE><<<grid, WA_THREADS, (size_t)A.p.lds_floats * 4, s>>>(A);
+    LBDRN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int MODE>
+static int dispatch_wapply(const WApplyArgs& A, int grid, hipStream_t s)
+{
+    const bool one = A.net.nl == 1;
+    if (A.p.NT == 8) return one ? launch_wapply<8, 1, MODE>(A, grid, s) : launch_wapply<8, 2, MODE>(A, grid, s);
+    return one ? launch_wapply<16, 1, MODE>(A, grid, s) : launch_wapply<16, 2, MODE>(A, grid, s);
+}
+
+static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const uint16_t* img,
+                      const uint16_t* msb, const float* params, uint16_t* out, float* y_out,
+                      double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
+{
+    WApplyArgs A;
+    if (!make_wapply_plan(g, net, &A.p)) {
+        set_error("shape not supported by the MFMA apply kernels");
+        return LBDRN_E_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < wapply_workspace(g, net)) {
+        set_error("apply workspace too small: %zu < %zu", ws_bytes, wapply_workspace(g, net));
+        return LBDRN_E_WORKSPACE;
+    }
+    float* packed = (float*)ws;
+    double* partial = (double*)((char*)ws + align_up((size_t)A.p.pack_floats * 4, 256));
+    k_pack_apply_wide<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, packed);
+    LBDRN_LAUNCH_CHECK();
+    A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
+    A.partial = partial;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess)
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    A.nvirt = std::min(std::min(A.p.tiles_x * A.p.tiles_y, cus), MFMA_PARTIALS);
+    const int grid = background ? std::max(1, A.nvirt / 2) : A.nvirt;
+    A.stamps = nullptr;
+#ifdef LBDRN_APPLY_STAMPS
+    static unsigned long long* wstamp_buf = nullptr;
+    if (!wstamp_buf) LBDRN_HIP_TRY(hipMalloc(&wstamp_buf, 1024 * 8 * sizeof(unsigned long long)));
+    A.stamps = wstamp_buf;
+#endif
+    int rc = mode == MODE_DECODE ? dispatch_wapply<MODE_DECODE>(A, grid, s) : dispatch_wapply<MODE_EVAL>(A, grid, s);
+    if (rc) return rc;
+    if (mode != MODE_DECODE) {
+        k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, A.nvirt, sse);
+        LBDRN_LAUNCH_CHECK();
+    }
+#ifdef LBDRN_APPLY_STAMPS
+    {
+        LBDRN_HIP_TRY(hipStreamSynchronize(s));
+        unsigned long long h[1024 * 8];
+        LBDRN_HIP_TRY(hipMemcpy(h, A.stamps, (size_t)grid * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double sum[8] = {};
+        for (int b = 0; b < grid; ++b) for (int k = 0; k < 8; ++k) sum[k] += (double)h[b * 8 + k];
+        const double segs = (double)A.p.tiles_x * A.p.tiles_y * A.p.TH * (TILE_W / 16) / 4 / grid;
+        double rtmin = 1e30, rtmax = 0;
+        for (int b = 0; b < grid; ++b) { rtmin = std::min(rtmin, (double)h[b * 8 + 6]); rtmax = std::max(rtmax, (double)h[b * 8 + 6]); }
+        fprintf(stderr, "[lbdrn wide apply stamps] wave lifetime %.2f .. %.2f ms (mean %.2f); per wave: tiles-staging %.0f total; per 16-px segment: L0 %.0f sin %.0f L1 %.0f last %.0f epilogue %.0f\n",
+                rtmin / 1e5, rtmax / 1e5, sum[6] / grid / 1e5, sum[0] / grid, sum[1] / grid / segs, sum[2] / grid / segs, sum[3] / grid / segs, sum[4] / grid / segs, sum[5] / grid / segs);
+    }
+#endif
+    return 0;
+}
+
 static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const uint16_t* img,
                      const uint16_t* msb, const float* params, uint16_t* out, float* y_out,
                      double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
 {
     ApplyArgs A;
-    if (!make_plan(g, net, &A.p)) {
-        set_error("shape not supported by the MFMA apply kernel");
-        return LBDRN_E_UNSUPPORTED;
-    }
+    if (!make_plan(g, net, &A.p))   // too wide for LDS-resident weights: the streaming kernel (apply_wide.inc)
+        return run_wapply(g, net, mode, img, msb, params, out, y_out, sse, ws, ws_bytes, background, s);
     if (!ws || ws_bytes < mfma_apply_workspace(g, net)) {
         set_error("apply workspace too small: %zu < %zu", ws_bytes, mfma_apply_workspace(g, net));
         return LBDRN_E_WORKSPACE;

@@ -9,7 +9,7 @@ from lbdrn_hip import codec, ops
 from lbdrn_hip.synth import synthetic_tile
 dev = torch.device("cuda:0")
 tiles = [ops.to_device_u16(synthetic_tile(i, 8, 2048, 2048), dev) for i in range(4)] * int(os.environ.get('AB_REPEAT', '2'))
-args = (5, 2, 64, 2, 1e-3, 8192, 10)
+args = (5, 2, int(os.environ.get('AB_BC', '64')), 2, 1e-3, 8192, 10)
 out = []
 for infl in [int(x) for x in os.environ.get('AB_INFLIGHT', '1,2').split(',')]:
     codec.fit_many(tiles[:max(2, infl)], *args, seed=19920517, in_flight=infl)   # every in-flight stream warm

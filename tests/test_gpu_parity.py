@@ -123,7 +123,11 @@ APPLY_CASES = [
     (8, 18, 35, 5, 2, 64, 2, (1, 0, 1, 1)),
     (4, 12, 65, 4, 2, 64, 2, (1, 1, 0, 1)),
     (2, 3, 4, 6, 2, 64, 2, (0, 0, 1, 1)),
-    (8, 24, 20, 5, 2, 256, 2, (0, 0, 1, 1)),   # bc=256: generic path only
+    (8, 24, 20, 5, 2, 256, 2, (0, 0, 1, 1)),   # bc=256 (BASELINE configs[2]): the streaming kernel k_apply_wide
+    (8, 21, 70, 5, 2, 256, 2, (1, 1, 1, 1)),   # bc=256 with the positional embedding (F=250: a group mixes both kinds)
+    (3, 19, 131, 4, 1, 256, 1, (1, 0, 1, 0)),  # bc=256, one hidden layer, coords without embedding, ragged tiles
+    (16, 9, 40, 6, 0, 256, 2, (0, 0, 1, 1)),   # bc=256, D=0, all 16 output slots
+    (8, 24, 20, 5, 2, 256, 3, (0, 0, 1, 1)),   # bc=256 nl=3: generic path only
 ]
 
 
@@ -142,14 +146,15 @@ def test_decode_and_eval_bit_exact_vs_oracle(dev, case):
     geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
     net = ops.make_net(F, bc, C, nl)
     p_d = torch.from_numpy(params).to(dev)
-    paths = [ops._lib.PATH_GENERIC] + ([ops._lib.PATH_MFMA] if bc <= 128 else [])
+    fused = bc <= 128 or nl <= 2
+    paths = [ops._lib.PATH_GENERIC] + ([ops._lib.PATH_MFMA] if fused else [])
     for path in paths:
         out, y = ops.decode_fused(geom, net, msb_d, p_d, want_y=True, path=path)
         assert np.array_equal(_bits(y.cpu().numpy()), _bits(y_o)), (case, path)
         assert np.array_equal(ops.from_device_u16(out), out_o), (case, path)
         sse = float(ops.eval_sse(geom, net, img_d, msb_d, p_d, path=path).item())
         assert abs(sse - sse_o) <= 1e-11 * max(1.0, abs(sse_o)), (case, path, sse, sse_o)
-    if bc > 128:
+    if not fused:
         with pytest.raises(ops._lib.LbdrnError):
             ops.decode_fused(geom, net, msb_d, p_d, path=ops._lib.PATH_MFMA)
 
@@ -185,8 +190,7 @@ def test_decode_big_rasters_hip_oracle_reference(golden, dev, tag):
     geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
     net = ops.make_net(cfg.feature_dim(C, D), bc, C, nl)
     p_d, msb_d = torch.from_numpy(G["params"]).to(dev), ops.to_device_u16(msb, dev)
-    paths = [ops._lib.PATH_GENERIC, ops._lib.PATH_AUTO] + ([ops._lib.PATH_MFMA] if bc <= 128 else [])
-    for path in paths:
+    for path in (ops._lib.PATH_GENERIC, ops._lib.PATH_AUTO, ops._lib.PATH_MFMA):
         out = ops.from_device_u16(ops.decode_fused(geom, net, msb_d, p_d, path=path))
         assert np.array_equal(out, out_o), (tag, path)
         bad = np.flatnonzero((out != ref).transpose(1, 2, 0).reshape(-1))
