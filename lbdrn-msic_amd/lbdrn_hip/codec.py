@@ -91,16 +91,26 @@ class DeviceFit:
 _RNG_LOCK = threading.Lock()   # the global torch CPU generator is one per process
 _POOL_LOCK = threading.Lock()
 _FIT_STREAMS = {}               # device -> streams the fits in flight run on
-_EVAL_STREAMS = {}              # (device, stream a fit runs on) -> the stream its evaluation passes run on
+_OVERLAP_OK = {}                # device -> True / False once a fit has measured whether background passes pay there
+
+
+def _fit_stream_pool(dev, n):
+    """The process-wide streams fits run on (kept for life: torch's allocator pools memory per stream), at least n."""
+    with _POOL_LOCK:
+        pool_ = _FIT_STREAMS.setdefault(dev, [])
+        while len(pool_) < n:
+            pool_.append(torch.cuda.Stream(device=dev))
+        return pool_
 
 
 def _eval_stream(dev, main):
-    """One evaluation stream per stream a fit runs on, kept for the life of the process (like _FIT_STREAMS)."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), main.cuda_stream)
-    with _POOL_LOCK:
-        if key not in _EVAL_STREAMS:
-            _EVAL_STREAMS[key] = torch.cuda.Stream(device=dev)
-        return _EVAL_STREAMS[key]
+    """The stream a lone fit's evaluation passes run on: one of the fit streams (none is busy when a fit is alone),
+    not a stream of its own -- a process that uses more streams than the device has hardware queues makes streams
+    share a queue, and a background pass that shares one with the training chain costs 3x the fit instead of
+    saving 5 % of it (measured: scripts/ab_streamidx.py)."""
+    for s in _fit_stream_pool(dev, 2):
+        if s.cuda_stream != main.cuda_stream:
+            return s
 
 
 def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1,
@@ -158,7 +168,11 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     main = torch.cuda.current_stream(dev)
     if os.environ.get("LBDRN_OVERLAP_EVAL") in ("0", "1"):   # A/B measurements
         alone = os.environ["LBDRN_OVERLAP_EVAL"] == "1"
-    side = _eval_stream(dev, main) if alone and eval_epochs else None
+    side = _eval_stream(dev, main) if alone and len(eval_epochs) > 1 and _OVERLAP_OK.get(dev, True) else None
+    # ... and since other users of the process may hold every hardware queue already, the fit checks once per device
+    # (without waiting for anything) that its second epoch, which has a pass beside it, was not much slower than its
+    # first; if it was, the passes go back into the chain
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if side is not None and dev not in _OVERLAP_OK else None
     snaps = torch.empty((max(len(eval_epochs), 1), params.numel()), dtype=torch.float32, device=dev)
     mses = torch.zeros((max(len(eval_epochs), 1),), dtype=torch.float32, device=dev)
     if side is not None:
@@ -166,6 +180,14 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     adam_steps = 0
     for e in range(1, epochs + 1):
         perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
+        if marks is not None:
+            if e <= 3:
+                marks[e - 1].record(main)
+            elif dev not in _OVERLAP_OK and marks[2].query():
+                _OVERLAP_OK[dev] = marks[1].elapsed_time(marks[2]) < 1.6 * marks[0].elapsed_time(marks[1])
+                if not _OVERLAP_OK[dev]:
+                    main.wait_stream(side)
+                    side = None
         ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
                         adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
         adam_steps += steps_per_epoch
@@ -181,6 +203,9 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
             out.evaluated.append(e)
     if side is not None:
         main.wait_stream(side)
+    if marks is not None and dev not in _OVERLAP_OK and epochs >= 3:   # a short fit: settle it now (the fit is over anyway)
+        marks[2].synchronize()
+        _OVERLAP_OK[dev] = marks[1].elapsed_time(marks[2]) < 1.6 * marks[0].elapsed_time(marks[1])
     best_params = params.clone() if epochs == 1 else draws_params0      # encode.py:100-103 / :91
     best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)   # encode.py:91
     for k, e in enumerate(eval_epochs):
@@ -228,12 +253,9 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
             # streams are kept for the life of the process: torch's caching allocator pools memory per stream,
             # so a fresh stream per call would send every fit's 3.5 GB workspace back to hipMalloc
             with _POOL_LOCK:
-                pool_ = _FIT_STREAMS.setdefault(img_d.device, [])
                 k = len(taken)
-                if k >= len(pool_):
-                    pool_.append(torch.cuda.Stream(device=img_d.device))
-                taken.append(pool_[k])
-                local.stream = pool_[k]
+                taken.append(None)
+            local.stream = _fit_stream_pool(img_d.device, k + 1)[k]
             local.stream.wait_stream(caller)
         with torch.cuda.stream(local.stream):
             fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,

@@ -61,6 +61,8 @@ if "k_train_wave_mfma_busy_frac_whole_chip" in out:
 out["algorithmic_bytes_per_train_launch"] = 8192 * 16
 out["note"] = ("k_train_wave: 128 workgroups of 64 rows on 128 CUs.  Traffic per launch = the 9.5 MB gradient slabs written through (128 x 18,688 "
                "floats) + the 6.8 MB row gather (8192 x 832 B from the materialised row matrix) + the weights once per XCD, against 131 KB of "
-               "algorithmic bytes: not HBM-bound (17.6 MB / 20.3 us = 0.87 TB/s); round 1's kernel moved 27.4 MB (256 slabs + the same rows)")
+               "algorithmic bytes: not HBM-bound (%.1f MB / %.1f us = %.2f TB/s); round 1's kernel moved 27.4 MB (256 slabs + the same rows)"
+               % (out.get("k_train_wave_hbm_bytes_per_launch", 0) / 1e6, out.get("k_train_wave_duration_us_in_counter_pass", 1.0),
+                  out.get("k_train_wave_hbm_bytes_per_launch", 0) / 1e6 / max(out.get("k_train_wave_duration_us_in_counter_pass", 1.0), 1e-9)))
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
