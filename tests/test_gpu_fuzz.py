@@ -82,6 +82,41 @@ def test_apply_fuzz_mfma_equals_generic_and_oracle(dev):
     assert ran >= 10 and checked_oracle >= 3, (ran, checked_oracle)
 
 
+def test_apply_fuzz_streaming_kernel_equals_generic_and_oracle(dev):
+    """bc = 256: k_apply_wide (weights streamed, 16-pixel waves) against the per-layer generic kernels, bit for bit, on
+    random geometries -- every constants.py switch, 1..16 bands, D 0..3, ragged tiles, one and two hidden layers."""
+    rng = np.random.default_rng(20261004)
+    checked_oracle = ran = 0
+    for it in range(20 * SOAK):
+        C, H, W, K, D, _, _, cfg, img = _random_case(rng, train=True)
+        nl = int(rng.integers(1, 3))
+        F = cfg.feature_dim(C, D)
+        msb = img >> K
+        mx = int(msb.max())
+        if mx == 0 or F > 400 or not cfg.use_colors:
+            continue
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(F, 256, C, nl)
+        p = torch.from_numpy(_params(rng, F, 256, C, nl, 2.5)).to(dev)
+        msb_d, img_d = ops.to_device_u16(msb, dev), ops.to_device_u16(img, dev)
+        a, ya = ops.decode_fused(geom, net, msb_d, p, want_y=True, path=MFMA)
+        b, yb = ops.decode_fused(geom, net, msb_d, p, want_y=True, path=GEN)
+        tag = (it, C, H, W, K, D, nl, vars(cfg))
+        assert torch.equal(a, b), tag
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), tag
+        s1 = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA).item()
+        s2 = ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item()
+        s3 = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA, background=True).item()
+        assert abs(s1 - s2) <= 1e-11 * max(s2, 1e-30) and s3 == s1, tag
+        ran += 1
+        if H * W <= 1500 and checked_oracle < 4:
+            ocfg = O.FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative)
+            ro = O.decode(msb, K, D, ocfg, p.cpu().numpy(), 256, nl, mx)
+            assert np.array_equal(ops.from_device_u16(a), ro), tag
+            checked_oracle += 1
+    assert ran >= 10 and checked_oracle >= 2, (ran, checked_oracle)
+
+
 def test_train_fuzz_mfma_matches_generic(dev):
     rng = np.random.default_rng(77)
     done = 0

@@ -297,6 +297,27 @@ def test_full_size_properties(dev):
     assert abs(np.sum(lsb_err ** 2) - s1) / s1 < 0.05
 
 
+def test_full_size_properties_wide_network(dev):
+    """BASELINE.json configs[2] size (bc = 256): the streaming apply kernel and the per-layer generic kernels agree bit
+    for bit on the 33.5 M decoded sub-pixels and to 1e-12 on the whole-image SSE; a background pass gives the same sum."""
+    C, H, W, K, D = 8, 2048, 2048, 5, 2
+    img = synthetic_tile(3, C, H, W)
+    img_d = ops.to_device_u16(img, dev)
+    msb_d, mx = ops.split_bits(img_d, K)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(200, 256, C, 2)
+    p = torch.from_numpy(_params(np.random.default_rng(2), 200, 256, C, 2) * 2.0).to(dev)
+    a = ops.decode_fused(geom, net, msb_d, p, path=MFMA)
+    b = ops.decode_fused(geom, net, msb_d, p, path=GEN)
+    assert torch.equal(a, b)
+    rec = ops.from_device_u16(a)
+    assert np.array_equal(rec >> K, img >> K)
+    s1 = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA).item()
+    s2 = ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item()
+    s3 = ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA, background=True).item()
+    assert abs(s1 - s2) <= 1e-12 * s2 and s3 == s1
+
+
 def test_full_size_fit_is_reproducible_and_self_consistent(dev):
     """BASELINE.json configs[1] end to end (2 epochs to keep it short): two runs give identical bits
     (fixed reduction orders, no atomics on the path); the evaluation MSE the fit selected on equals the MSE
