@@ -13,7 +13,8 @@
 // chain that walks to ever earlier steps (one hop on average).  So:
 //   1. one wave runs the MT19937 recurrence and emits the raw words; the targets j_i are made of them by
 //      4 M threads;  2. the steps are bucketed by target (count, exclusive scan, scatter);
-//   3. every position chases its chain through the buckets, independently.
+//   3. every position chases its chain, independently (k_links prepares one array for the first hop and one for the
+//      later ones from the buckets).
 // Bucket order is irrelevant (each hop takes the maximum step below a bound), so the atomics used to
 // fill the buckets do not affect the result.  tests/test_gpu_randperm.py checks equality with
 // torch.randperm for many (seed, n).
@@ -125,22 +126,43 @@ __global__ void __launch_bounds__(256)
     }
 }
 
+// The chains, two random accesses per index instead of nine: position p walks its own (small, contiguous) bucket once
+// and leaves, for every step x in it, the latest earlier step with the same target (pred[x]: the first hop of x's
+// chain), and for itself the latest step below p that targets it (last[p]: every later hop -- the steps that target
+// p are <= p).  last overwrites cnt in place (each thread reads only its own count), pred takes the dead cursor array.
 __global__ void __launch_bounds__(256)
-    k_chase(const uint32_t* __restrict__ j, uint32_t n, const uint32_t* __restrict__ off,
-            const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ entries, int64_t* __restrict__ out)
+    k_links(uint32_t n, const uint32_t* __restrict__ off, uint32_t* cnt_last, const uint32_t* __restrict__ entries,
+            int32_t* __restrict__ pred)
+{
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t b = off[p], e = b + cnt_last[p];
+    int32_t last = -1;
+    for (uint32_t k = b; k < e; ++k) {
+        const uint32_t x = entries[k];
+        int32_t best = -1;
+        for (uint32_t m = b; m < e; ++m) {
+            const uint32_t y = entries[m];
+            if (y < x && (int32_t)y > best) best = (int32_t)y;
+        }
+        pred[x] = best;
+        if (x < p && (int32_t)x > last) last = (int32_t)x;
+    }
+    cnt_last[p] = (uint32_t)last;
+    if (p == n - 1) pred[p] = last;   // the last position is nobody's step: its chain starts at its own bucket
+}
+
+__global__ void __launch_bounds__(256)
+    k_chase(const uint32_t* __restrict__ j, uint32_t n, const int32_t* __restrict__ pred,
+            const int32_t* __restrict__ last, int64_t* __restrict__ out)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint32_t p = j[i], t = i;
-    for (;;) {
-        const uint32_t b = off[p], e = b + cnt[p];
-        int64_t best = -1;
-        for (uint32_t k = b; k < e; ++k) {
-            const uint32_t s = entries[k];
-            if (s < t && (int64_t)s > best) best = s;
-        }
-        if (best < 0) break;
-        p = t = (uint32_t)best;
+    int32_t s = pred[i];
+    uint32_t p = j[i];
+    while (s >= 0) {
+        p = (uint32_t)s;
+        s = last[p];
     }
     out[i] = p;
 }
@@ -213,7 +235,9 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
             k_fill_buckets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, w.off, w.cursor, w.entries);
             LBDRN_LAUNCH_CHECK();
         }
-        k_chase<<<(un + 255) / 256, 256, 0, s>>>(j, un, w.off, w.cnt, w.entries, out + (size_t)c * n);
+        k_links<<<(un + 255) / 256, 256, 0, s>>>(un, w.off, w.cnt, w.entries, (int32_t*)w.cursor);
+        LBDRN_LAUNCH_CHECK();
+        k_chase<<<(un + 255) / 256, 256, 0, s>>>(j, un, (const int32_t*)w.cursor, (const int32_t*)w.cnt, out + (size_t)c * n);
         LBDRN_LAUNCH_CHECK();
     }
     return 0;
