@@ -226,9 +226,9 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time, each on
     its own stream and host thread (in_flight=None: 4); returns [then(fit) or fit, ...] in input order.
 
-    Why: one fit is a strict chain of short dependent kernels (train 20 us on half the chip -> reduce/Adam 5 us
+    Why: one fit is a strict chain of short dependent kernels (train 19 us on half the chip -> reduce/Adam 5 us
     -> train ...); independent chains side by side fill the other half and the holes (measured per 8 x 2048^2
-    tile: 157 ms alone, 98 with two, 84 with four in flight; more adds nothing).  Images are independent
+    tile: 137 ms alone, 92 with two, 77 with four in flight; more adds nothing).  Images are independent
     fits and every fit seeds the generator itself (`seed`, what each encode.py invocation does,
     ref encode.py:200-205), so results are bit-identical to fitting them one after another.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
