@@ -454,6 +454,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "single_tile_ms", "records"):
         assert key in d, key
     assert len(d["records"]) == d["n_gpus"] * d["steps"] and d["single_tile_ms"] > 0
+    assert 0 < d["single_tile_decode_ms"] < d["single_tile_encode_ms"] < d["single_tile_ms"]
     assert d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
