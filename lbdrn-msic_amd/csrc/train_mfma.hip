@@ -51,10 +51,12 @@ constexpr int TBC = 64;      // hidden width this kernel is built for
 constexpr int HP = 68;       // [sample][64] rows: 17 chunks of 16 B
 constexpr int TP = 36;       // [unit][32 samples] rows: 9 chunks of 16 B
 constexpr int OP = 20;       // [sample][16 channel slots] rows: 5 chunks
-constexpr int RED_SLICES = 8;   // workgroup slices per reduce block: 8 x 32 float4 lanes = 512 B per slab and block.
-                                // A/B (scripts/ab_inflight.py): 32 slices are 2.8 ms per tile faster for one fit at a time,
-                                // 8 slices 5 ms faster with two fits in flight (fewer, longer blocks disturb the other
-                                // fit's train kernel less); 4 and 64 lose both ways
+#ifndef LBDRN_RED_SLICES
+#define LBDRN_RED_SLICES 8
+#endif
+constexpr int RED_SLICES = LBDRN_RED_SLICES;   // workgroup slices per reduce block: 8 x 32 float4 lanes = 512 B per slab and block.
+                                // A/B with the round-2 kernels (128 slabs; scripts/ab_lib.sh, ms per tile for one fit alone /
+                                // four in flight): 8 slices 136 / 76-80, 4: 144 / 76, 16: 144 / 77-78, 32: 140 / 77
 constexpr int RED_LANES = 256 / RED_SLICES;  // float4 lanes per reduce block
 constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample tile st = 0..1)
 
