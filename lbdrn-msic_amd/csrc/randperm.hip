@@ -94,8 +94,16 @@ __global__ void __launch_bounds__(64) k_mt19937_raw(SeedList seeds, uint32_t n, 
                 st[k] = v;
                 if (whole || base + (uint32_t)k < steps) dst[64 * c] = v;
             }
+            // the look-ahead reads below take words OTHER lanes have just stored (x[k+1], the renewed x[k-227]):
+            // within one thread the addresses are disjoint, so without this the compiler may hoist them above the
+            // store they depend on -- the hardware keeps a wave's LDS operations in order, the compiler has to be
+            // told (wave-scope fence + scheduling barrier: no instruction is emitted for either)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (c + 3 < NC) { m[c + 3] = st[midx[c + 3]]; b[c + 3] = st[bidx[c + 3]]; }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // block boundary: the next block's first reads
+        __builtin_amdgcn_wave_barrier();
     };
     uint32_t base = 0;
     for (; base + MT_N <= steps; base += MT_N) block(base, true);

@@ -239,9 +239,19 @@ inline float predict(float prev)
 
 size_t weights_bound(int64_t n) { return 64 + (size_t)n * 6; }
 
+// fpzip switches to a narrow residual coder (one symbol per residual, no raw bits) at precisions of 8 bits and
+// below; this restatement has only the wide one, so those precisions are refused on both sides instead of writing
+// or reading a stream in the wrong syntax
+static constexpr unsigned FPZ_NARROW_MAX = 8;
+
 int weights_encode(const float* values, int64_t n, int precision, uint8_t* out, size_t cap, size_t* nbytes)
 {
     const unsigned prec = precision == 0 ? 32 : (unsigned)precision;
+    if (prec <= FPZ_NARROW_MAX || prec > 32) {
+        set_error("weight payload: precision %d outside (8, 32] (fpzip's narrow coder for <= 8 bits is not implemented)", precision);
+        return LBDRN_E_UNSUPPORTED;
+    }
+    if (n < 0 || n > 0xFFFFFFFFll) { set_error("weight payload: %lld values", (long long)n); return LBDRN_E_ARG; }
     std::vector<uint8_t> buf;
     buf.reserve((size_t)n * 3 + 64);
     RangeEncoder re(buf);
@@ -294,7 +304,7 @@ int weights_info(const uint8_t* in, size_t nbytes, int64_t* n, int* precision)
     (void)rd.raw(8);
     const uint32_t type = rd.raw(1), prec = rd.raw(7);
     const uint32_t nx = rd.raw_wide(32), ny = rd.raw_wide(32), nz = rd.raw_wide(32), nf = rd.raw_wide(32);
-    if (type != 0 || prec < 2 || prec > 32 || rd.overrun) {
+    if (type != 0 || prec <= FPZ_NARROW_MAX || prec > 32 || rd.overrun) {
         set_error("weight payload: unsupported fpzip stream (type %u, precision %u)", type, prec);
         return LBDRN_E_UNSUPPORTED;
     }
@@ -340,6 +350,12 @@ int weights_decode(const uint8_t* in, size_t nbytes, float* values, int64_t cap)
         values[k] = prev;
     }
     if (rd.overrun) { set_error("weight payload is truncated"); return LBDRN_E_ARG; }
+    // a well-formed stream ends with the coder's four flush bytes, all of them already pulled into `code`: a decoder
+    // that stops anywhere else was fed a damaged stream (or trailing bytes that are not part of it)
+    if (rd.p != rd.end) {
+        set_error("weight payload: %zu bytes left behind the last value", (size_t)(rd.end - rd.p));
+        return LBDRN_E_ARG;
+    }
     return 0;
 }
 

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 import logger
-from lbdrn_hip import codec, container, raster_io, shard
+from lbdrn_hip import codec, container, ops, raster_io, shard
 from lbdrn_hip.features import FeatCfg
 from LBDRNdataset import tile_windows, write_tiff_with_gdal
 
@@ -33,8 +33,12 @@ def test(bitstream, dirname, filename, nn_bytes, base_bytes, write=True):
     nn_payload, bitstream = bitstream[:nn_bytes], bitstream[nn_bytes:]
     base_payload, bitstream = bitstream[:base_bytes], bitstream[base_bytes:]
     base = container.decode_base(base_payload, device=DEVICE, keep_on_device=True)   # ref decode.py:69-73
-    params = container.decode_weights(nn_payload)
-    image = codec.apply_image(base, params, K, D, bc, nl, cfg=FeatCfg.from_constants(), device=DEVICE)
+    cfg = FeatCfg.from_constants()
+    # the parameter count the header's network shape needs: a payload that holds another number is refused before
+    # anything is sized by it (ref decode.py:114-120 slices the vector by state_dict shapes)
+    need = ops.param_count(ops.make_net(cfg.feature_dim(int(base.shape[0]), D), bc, int(base.shape[0]), nl))
+    params = container.decode_weights(nn_payload, expected=need)
+    image = codec.apply_image(base, params, K, D, bc, nl, cfg=cfg, device=DEVICE)
     recon_path = f"{dirname}/{filename}_recon.tif"
     test.last_image = image
     if write:

@@ -5,9 +5,9 @@ Header layout (ref encode.py:37-64, decode.py:25-53), big-endian:
   nn_bytes:u24 x sr^2   base_bytes:u32 x sr^2
 The two payload codecs of the reference are third-party programs that are absent from this image
 (fpzip 1.2.4 for the weights, GDAL/OpenJPEG lossless JP2 for the MSB plane).
-  * weights: an fpzip stream -- fpzip's own when the module is importable, otherwise written / read by this
-    package's restatement of the published algorithm (csrc/weights_codec.hip; byte compatibility with fpzip is
-    unverified: parity unpinned);
+  * weights: an fpzip stream, always written and read by this package's restatement of the published algorithm
+    (csrc/weights_codec.hip; byte compatibility with fpzip is unverified here: parity unpinned) and cross-checked
+    against the fpzip module wherever that is importable;
   * MSB plane: always this package's own tagged format (LBB2, coded on the GPU; LBB1, the older host codec): JPEG 2000
     syntax is not produced or read, with or without GDAL.  bpsp figures are therefore not comparable with the
     reference's published ones; MSE / PSNR are.
@@ -96,7 +96,7 @@ def truncate_precision(flat, precision):
     if precision in (0, 32):
         return flat.astype(np.float32).copy()
     if not 2 <= precision < 32:
-        raise ValueError(f"precision {precision} outside [2,32]")
+        raise ValueError(f"precision {precision} outside [2,32]")   # (the payload coder itself takes 9..32)
     mask = np.uint32((0xFFFFFFFF << (32 - precision)) & 0xFFFFFFFF)
     return (flat.astype(np.float32).view(np.uint32) & mask).view(np.float32)
 
@@ -109,14 +109,10 @@ def _fpzip_module():
         return None
 
 
-def encode_weights(flat, precision):
-    """The float32 parameter vector as a 1-D fpzip stream (ref encode.py:129).  With the fpzip module installed it
-    is fpzip's own output; otherwise the stream is written by lbdrn_weights_encode, this package's restatement of
-    the published algorithm (same syntax as far as can be known here: parity unpinned)."""
-    flat = np.ascontiguousarray(flat, dtype=np.float32)
-    fpzip = _fpzip_module()
-    if fpzip is not None:
-        return fpzip.compress(flat, precision=precision, order="C")
+MAX_WEIGHT_VALUES = 1 << 27   # what decode_weights will allocate for when the caller names no expected count
+
+
+def _native_encode(flat, precision):
     import ctypes
     from . import _lib
     L = _lib.lib()
@@ -128,12 +124,65 @@ def encode_weights(flat, precision):
     return bytes(out[:nbytes.value])
 
 
-def decode_weights(buf):
-    """Weight payload -> float32 vector (ref decode.py:113).  Streams of earlier builds (tag LBW1: byte planes +
-    zlib) still decode."""
+def _native_decode(buf, expected):
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    n, prec = ctypes.c_int64(), ctypes.c_int32()
+    _lib.check(L.lbdrn_weights_info(buf, len(buf), ctypes.byref(n), ctypes.byref(prec)))
+    # the count comes from the stream: checked against what the network needs (or a fixed ceiling) BEFORE anything
+    # is allocated by it (a damaged header could ask for 16 GB)
+    if expected is not None and n.value != expected:
+        raise _lib.LbdrnError(f"weight payload holds {n.value} values, the network needs {expected}")
+    if n.value > MAX_WEIGHT_VALUES:
+        raise _lib.LbdrnError(f"weight payload claims {n.value} values")
+    out = np.empty(n.value, np.float32)
+    _lib.check(L.lbdrn_weights_decode(buf, len(buf), out.ctypes.data_as(ctypes.c_void_p), out.size))
+    return out
+
+
+def encode_weights(flat, precision):
+    """The float32 parameter vector as a 1-D fpzip stream (ref encode.py:129: fpzip.compress(params, precision=16,
+    order='C')).
+
+    WHO writes the stream does not depend on what happens to be installed: it is always lbdrn_weights_encode, this
+    package's restatement of the published algorithm (parity unpinned), so a .bin written here is
+    decoded by the same code that wrote it on every box.  Where the fpzip module is importable the stream is
+    cross-checked on the spot -- fpzip must decode it to exactly the truncated values -- and a disagreement raises
+    instead of shipping a payload the reference could not read.  LBDRN_WEIGHTS_CODEC=fpzip hands the job to the
+    module itself (the reference's own bytes, for interchange experiments).  Precisions <= 8 are refused: fpzip
+    codes them with a narrow residual coder this package does not restate."""
+    import os
+    flat = np.ascontiguousarray(flat, dtype=np.float32)
+    fpzip = _fpzip_module()
+    if os.environ.get("LBDRN_WEIGHTS_CODEC") == "fpzip":
+        if fpzip is None:
+            raise RuntimeError("LBDRN_WEIGHTS_CODEC=fpzip, but the fpzip module is not importable")
+        return fpzip.compress(flat, precision=precision, order="C")
+    stream = _native_encode(flat, precision)
+    if fpzip is not None and flat.size:
+        back = np.asarray(fpzip.decompress(stream, order="C"), dtype=np.float32).reshape(-1)
+        want = truncate_precision(flat, precision)
+        if back.size != want.size or not np.array_equal(back.view(np.uint32), want.view(np.uint32)):
+            raise RuntimeError("the installed fpzip does not decode this package's weight stream to the same values: "
+                               "the restated syntax differs from fpzip's (set LBDRN_WEIGHTS_CODEC=fpzip to write with "
+                               "the module)")
+    return stream
+
+
+def decode_weights(buf, expected=None):
+    """Weight payload -> float32 vector (ref decode.py:113).  `expected`: the parameter count the header's network
+    shape needs; a stream that holds another number is refused before anything is allocated.
+
+    Deterministic like encode_weights: this package's decoder reads the stream; where the fpzip module is importable
+    its answer is compared and a difference raises (a stream written by real fpzip in a syntax this restatement
+    gets wrong would otherwise become silently wrong weights).  A stream this package's decoder refuses is handed to
+    fpzip when present.  Streams of earlier builds (tag LBW1: byte planes + zlib) still decode."""
     buf = bytes(buf)
     if buf[:4] == NN_PRIVATE_MAGIC:
         precision, count = struct.unpack_from(">BI", buf, 4)
+        if expected is not None and count != expected:
+            raise ValueError(f"weight payload holds {count} values, the network needs {expected}")
         nbytes = 4 if precision in (0, 32) else (precision + 7) // 8
         raw = np.frombuffer(zlib.decompress(buf[9:]), np.uint8).reshape(nbytes, count)
         q = np.zeros(count, np.uint32)
@@ -141,15 +190,20 @@ def decode_weights(buf):
             q |= raw[i].astype(np.uint32) << np.uint32(24 - 8 * i)
         return q.view(np.float32)
     fpzip = _fpzip_module()
-    if fpzip is not None:
-        return np.asarray(fpzip.decompress(buf, order="C")[0][0][0], dtype=np.float32)
-    import ctypes
     from . import _lib
-    L = _lib.lib()
-    n, prec = ctypes.c_int64(), ctypes.c_int32()
-    _lib.check(L.lbdrn_weights_info(buf, len(buf), ctypes.byref(n), ctypes.byref(prec)))
-    out = np.empty(n.value, np.float32)
-    _lib.check(L.lbdrn_weights_decode(buf, len(buf), out.ctypes.data_as(ctypes.c_void_p), out.size))
+    try:
+        out = _native_decode(buf, expected)
+    except _lib.LbdrnError:
+        if fpzip is None:
+            raise
+        out = None
+    if fpzip is not None:
+        theirs = np.asarray(fpzip.decompress(buf, order="C"), dtype=np.float32).reshape(-1)
+        if expected is not None and theirs.size != expected:
+            raise ValueError(f"weight payload holds {theirs.size} values, the network needs {expected}")
+        if out is not None and (theirs.size != out.size or not np.array_equal(theirs.view(np.uint32), out.view(np.uint32))):
+            raise RuntimeError("fpzip and this package's decoder read different weights from the same stream")
+        out = theirs if out is None else out
     return out
 
 

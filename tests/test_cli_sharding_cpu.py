@@ -72,7 +72,7 @@ def _decode_worker(rank, world, port, bin_path, org):
     import decode
     from lbdrn_hip import codec, container
     codec.apply_image = _stub_apply
-    container.decode_weights = lambda payload: np.zeros(4, np.float32)
+    container.decode_weights = lambda payload, expected=None: np.zeros(4, np.float32)
     container.decode_base = lambda payload, device=None, keep_on_device=False: np.frombuffer(payload[:48], np.uint8).reshape(2, 4, 6).copy()
     assert decode.main(["-i", bin_path, "-org", org]) == 0
 
@@ -122,7 +122,7 @@ def test_tile_sharded_decode_equals_serial(tmp_path, monkeypatch):
         (d / "img.bin").write_bytes(blob)
         if mode == "serial":
             monkeypatch.setattr(codec, "apply_image", _stub_apply)
-            monkeypatch.setattr(container, "decode_weights", lambda payload: np.zeros(4, np.float32))
+            monkeypatch.setattr(container, "decode_weights", lambda payload, expected=None: np.zeros(4, np.float32))
             monkeypatch.setattr(container, "decode_base",
                                 lambda payload, device=None, keep_on_device=False: np.frombuffer(payload[:48], np.uint8).reshape(2, 4, 6).copy())
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):

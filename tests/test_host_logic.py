@@ -177,7 +177,7 @@ def test_weight_payload_value_map_on_every_class_of_float():
     assert np.isnan(t16[15:17].view(np.float32)).all()                      # quiet NaNs stay NaN
     rng = np.random.default_rng(5)
     big = np.concatenate([w, rng.normal(0, 0.05, 5000).astype(np.float32), np.zeros(40, np.float32)])
-    for prec in (16, 2, 9, 24, 32, 0):
+    for prec in (16, 9, 12, 24, 32, 0):
         stream = c.encode_weights(big, prec)
         bits = big.view(np.uint32)
         expect = c.truncate_precision(big, prec).view(np.uint32)
@@ -195,13 +195,41 @@ def test_weight_payload_value_map_on_every_class_of_float():
     with pytest.raises(_lib.LbdrnError):
         c.decode_weights(good[:len(good) // 2])
     assert c.decode_weights(c.encode_weights(np.zeros(0, np.float32), 16)).size == 0
+    # the count in the stream is checked against what the network needs before anything is allocated by it
+    with pytest.raises(_lib.LbdrnError):
+        c.decode_weights(good, expected=big.size + 1)
+    assert c.decode_weights(good, expected=big.size).size == big.size
+    # bytes behind the coder's flush are not part of a stream
+    with pytest.raises(_lib.LbdrnError):
+        c.decode_weights(good + b"\0\0")
+    # fpzip codes precisions <= 8 with a narrow residual coder that is not restated here: refused on both sides
+    for prec in (2, 8):
+        with pytest.raises(_lib.LbdrnError):
+            c.encode_weights(big, prec)
+
+
+@pytest.mark.skipif(__import__("importlib").util.find_spec("fpzip") is None, reason="fpzip is not installed here")
+def test_weight_payload_is_fpzips_own_bytes_where_fpzip_exists():
+    """Runs only on a box that has the fpzip module (none in this image: parity unpinned until it does): the
+    restated coder and fpzip must write the same bytes and read each other's streams."""
+    import fpzip
+    from lbdrn_hip import container as c
+    rng = np.random.default_rng(11)
+    w = np.concatenate([rng.normal(0, 0.05, 17544), np.zeros(64)]).astype(np.float32)
+    for prec in (9, 16, 24, 32):
+        ours = c._native_encode(w, prec)
+        theirs = fpzip.compress(w, precision=prec, order="C")
+        assert ours == theirs, prec
+        want = c.truncate_precision(w, prec).view(np.uint32)
+        assert np.array_equal(np.asarray(fpzip.decompress(ours, order="C"), np.float32).reshape(-1).view(np.uint32), want)
+        assert np.array_equal(c._native_decode(theirs, w.size).view(np.uint32), want)
 
 
 def test_payload_round_trips_and_precision_model():
     from lbdrn_hip import container as c
     rng = np.random.default_rng(0)
     w = rng.normal(0, 0.1, 17544).astype(np.float32)
-    for prec in (16, 20, 32, 8):
+    for prec in (16, 20, 32, 9):
         q = c.decode_weights(c.encode_weights(w, prec))
         assert np.array_equal(q.view(np.uint32), c.truncate_precision(w, prec).view(np.uint32))
     assert np.all(c.truncate_precision(w, 16).view(np.uint32) & 0xFFFF == 0)
