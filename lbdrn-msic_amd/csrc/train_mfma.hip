@@ -37,6 +37,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -91,7 +92,7 @@ struct TrainPlan {
     int64_t NP;
     int64_t offW[5], offB[5];  // canonical parameter offsets per layer (index nl = last layer)
     int pk_w0, pk_wh, pk_wl, pack_floats;  // fragment-order buffer (floats)
-    int wave;                  // 1: the wave-local kernel runs this shape (fragment orders differ, see frag_pos)
+    int wave;                  // 2: k_train_stream, 1: k_train_wave, 0: the tile kernel (fragment orders differ, see frag_pos)
     int pk_wht, pk_wlt;        // wave-local kernel: W_l^T and W_last^T fragments for the backward products
     int w_dp, w_df;            // 64 / (RP/4) and 64 % (RP/4): chunk walk of the row copy
     int wave_lds_floats;
@@ -99,18 +100,43 @@ struct TrainPlan {
     int lds_x, lds_xt, lds_h, lds_ht, lds_z, lds_zt, lds_zo, lds_zot, lds_pix, lds_red, lds_floats;
 };
 
+// which fused step runs a shape this file supports: 2 = k_train_stream (default), 1 = k_train_wave (round 2's kernel),
+// 0 = the 8-wave tile kernel k_train_mfma (nl = 3).  LBDRN_TRAIN_KERNEL = "tile" / "wave" forces an older one for A/B
+// measurements; it is read ONCE per process (the choice fixes the row-matrix layout that lbdrn_train_prepare builds
+// and lbdrn_train_epoch reads: it must not change between the two).
+static int train_kernel_choice()
+{
+    static const int choice = [] {
+        const char* e = getenv("LBDRN_TRAIN_KERNEL");
+        if (!e) return 2;
+        return e[0] == 't' ? 0 : e[0] == 'w' ? 1 : 2;
+    }();
+    return choice;
+}
+
+__host__ __device__ constexpr int stream_rp(int LQ);
+struct StreamLds;
+static int stream_lds_total(int LQ, int NL);
+
 static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan* out)
 {
     if (net.bc != TBC || net.nl < 1 || net.nl > 3 || net.C > 16 || net.F < 1) return false;
     TrainPlan p;
     p.RP = (net.F + net.C + 3) / 4 * 4;
     p.LQ = 0;
-    for (int lq : {16, 32, 52, 64})
-        if (net.F <= 4 * lq && p.RP <= 4 * lq + 4) { p.LQ = lq; break; }
+    int kind = net.nl <= 2 ? train_kernel_choice() : 0;
+    if (kind == 2) {   // the streamed step: features in 4 LQ slots, labels in a group of their own
+        for (int lq : {16, 32, 52, 64})
+            if (net.F <= 4 * lq) { p.LQ = lq; break; }
+        if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 1; p.LQ = 0; }
+    }
+    if (kind != 2)
+        for (int lq : {16, 32, 52, 64})
+            if (net.F <= 4 * lq && p.RP <= 4 * lq + 4) { p.LQ = lq; break; }
     if (!p.LQ) return false;
     p.XP = 4 * p.LQ + 4;
     p.NT0 = (net.F + 15) / 16;
-    if (16 * p.NT0 > p.XP) return false;
+    if (kind != 2 && 16 * p.NT0 > p.XP) return false;
     p.NP = param_count(net);
     int64_t o = 0;
     for (int l = 0; l < net.nl; ++l) {
@@ -127,20 +153,26 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.pk_wht = k; k += (net.nl - 1) * 4 * 16 * 64;
     p.pk_wlt = k; k += 16 * 64;
     p.pack_floats = k;
-    {   // wave-local kernel: X [64][XP] + H, Z [nl][64][80] + Zo [64][16] + 4 doubles
+    p.w_dp = p.w_df = 0;
+    p.wave_lds_floats = 0;
+    if (kind == 2) {
+        p.RP = stream_rp(p.LQ);   // the matrix in the order layer 0 eats it (train_stream.inc)
+        p.wave_lds_floats = stream_lds_total(p.LQ, net.nl);
+    } else if (kind == 1) {   // wave-local kernel: X [64][XP] + H, Z [nl][64][80] + Zo [64][16] + 4 doubles
         const int xp = wave_xp(p.LQ);
         p.wave_lds_floats = WB * xp + WB * WHP + std::max(p.LQ * 256, wave_region_floats(net.nl));
-        p.wave = net.nl <= 2 && p.RP <= xp && 16 * p.NT0 <= xp && (size_t)p.wave_lds_floats * 4 <= 160 * 1024;
-        const char* force = getenv("LBDRN_TRAIN_KERNEL");     // "tile": the 8-wave tile kernel (A/B measurements)
-        if (force && force[0] == 't') p.wave = 0;
+        if (!(p.RP <= xp && 16 * p.NT0 <= xp && (size_t)p.wave_lds_floats * 4 <= 160 * 1024)) kind = 0;
         // the wave-local kernel brings its rows in by LDS-DMA, which wants the matrix row pitch equal to the LDS row
         // pitch (a wave's 16 rows are then one lane-linear piece): the row matrix is padded to it (config 1: 208 = 208;
         // positional embedding, F = 250: 260 -> 272 floats, 4.6 % more rows traffic for a prologue without registers)
-        if (p.wave) p.RP = xp;
-        const int rp4 = p.RP / 4;
-        p.w_dp = 64 / rp4;
-        p.w_df = 64 % rp4;
+        if (kind == 1) {
+            p.RP = xp;
+            const int rp4 = p.RP / 4;
+            p.w_dp = 64 / rp4;
+            p.w_df = 64 % rp4;
+        }
     }
+    p.wave = kind;
     int s = 4 * p.NT0 * 256;
     p.sl_hid = s; s += (net.nl - 1) * 16 * 256;
     p.sl_out = s; s += 4 * 256;
@@ -158,7 +190,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.lds_pix = f; f += TB;
     p.lds_red = f; f += 16;
     p.lds_floats = f;
-    if ((size_t)f * 4 > 160 * 1024) return false;
+    if (kind == 0 && (size_t)f * 4 > 160 * 1024) return false;
     *out = p;
     return true;
 }
@@ -203,20 +235,38 @@ size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 
 // ------------------------------------------------------------------ helper kernels
 
-// rows[n][0..F) = features of pixel n, rows[n][F..F+C) = labels, rest 0
+// what sits at position `pos` of a row of the streamed step's matrix (LQs = its quarter length; 0: rows are
+// features | labels in index order): a row is LQs/4 groups of 16 floats, group g = [quarter kq][e] = feature
+// kq LQs + 4 g + e -- what MFMA group g of layer 0 multiplies -- then one group of 16 label slots.
+// Returns the feature index, F + channel for a label, or -1 (a zero).
+__device__ __forceinline__ int row_source(int pos, int LQs, int F, int C)
+{
+    if (LQs == 0) return pos < F + C ? pos : -1;
+    const int g = pos >> 4;
+    if (g < (LQs >> 2)) {
+        const int f = ((pos >> 2) & 3) * LQs + 4 * g + (pos & 3);
+        return f < F ? f : -1;
+    }
+    const int ch = pos - 4 * LQs;
+    return ch < C ? F + ch : -1;
+}
+
+// rows[n][0..F) = features of pixel n, rows[n][F..F+C) = labels, rest 0 (LQs > 0: the same values in the streamed
+// step's order, row_source)
 // (ref LBDRNdataset.py:95-97, 104-131 -- the reference's own [N,F] / [N,C] matrices, side by side)
 __global__ void __launch_bounds__(256)
-    k_build_rows(lbdrn_geom g, int F, int RP, const uint16_t* __restrict__ msb,
+    k_build_rows(lbdrn_geom g, int F, int RP, int LQs, const uint16_t* __restrict__ msb,
                  const uint16_t* __restrict__ img, float* __restrict__ rows)
 {
     const int64_t HW = (int64_t)g.H * g.W;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= HW * RP) return;
     const int64_t pix = e / RP;
-    const int f = (int)(e - pix * RP);
+    const int f = row_source((int)(e - pix * RP), LQs, F, g.C);
     const int y = (int)(pix / g.W), x = (int)(pix - (int64_t)y * g.W);
     float v = 0.0f;
-    if (f < g.P) {
+    if (f < 0) {
+    } else if (f < g.P) {
         v = g.rowtab[(int64_t)y * g.P + f];
     } else if (f < 2 * g.P) {
         v = g.coltab[(int64_t)x * g.P + (f - g.P)];
@@ -245,7 +295,7 @@ __global__ void __launch_bounds__(256)
 // index divisions and scattered uint16 gathers: 0.7 TB/s; this one is bound by the 3.5 GB it writes).
 constexpr int BR_TW = 64;
 __global__ void __launch_bounds__(256)
-    k_build_rows_tiled(lbdrn_geom g, int F, int RP, const uint16_t* __restrict__ msb,
+    k_build_rows_tiled(lbdrn_geom g, int F, int RP, int LQs, const uint16_t* __restrict__ msb,
                        const uint16_t* __restrict__ img, float* __restrict__ rows)
 {
     extern __shared__ float br_lds[];
@@ -282,11 +332,13 @@ __global__ void __launch_bounds__(256)
     float* out = rows + ((int64_t)y * g.W + x0) * RP;
     const int64_t pix0 = (int64_t)y * g.W + x0;
     // element e' = pix*RP + f of the tile, walked with stride 256 without a division per element
-    int pix = tid / RP, f = tid - pix * RP;
+    int pix = tid / RP, pos = tid - pix * RP;
     const int dp = 256 / RP, df = 256 - dp * RP;
     for (int e = tid; pix < tw; e += 256) {
+        const int f = row_source(pos, LQs, F, g.C);
         float v = 0.0f;
-        if (f < g.P) {
+        if (f < 0) {
+        } else if (f < g.P) {
             v = g.rowtab[(int64_t)y * g.P + f];
         } else if (f < 2 * g.P) {
             v = g.coltab[(int64_t)(x0 + pix) * g.P + (f - g.P)];
@@ -299,8 +351,8 @@ __global__ void __launch_bounds__(256)
         }
         out[e] = v;
         pix += dp;
-        f += df;
-        if (f >= RP) { f -= RP; pix += 1; }
+        pos += df;
+        if (pos >= RP) { pos -= RP; pix += 1; }
     }
 }
 
@@ -1367,6 +1419,10 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #endif
 }
 
+#include "train_stream.inc"
+
+static int stream_lds_total(int LQ, int NL) { return stream_lds(LQ, NL).total; }
+
 #include "train_wide.inc"
 
 static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net)
@@ -1383,21 +1439,28 @@ static size_t wide_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 
 // ------------------------------------------------------------------ host driver
 
+// the dynamic-LDS ceiling of a kernel is told to the runtime once per device and kernel (a cache of an idempotent
+// setting; several host threads may get here together)
+template <class K>
+static int configure_lds_once(K kern, int bytes, std::atomic<unsigned long long>& configured)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured.load(std::memory_order_relaxed) & bit)) {
+        LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured.fetch_or(bit, std::memory_order_relaxed);
+    }
+    return 0;
+}
+
 template <int LQ, int NL>
 static int launch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
     auto kern = k_train_mfma<LQ, NL>;
     const size_t lds_bytes = (size_t)A.p.lds_floats * 4;
-    // told to the runtime once per device and kernel (a cache of an idempotent setting)
     static std::atomic<unsigned long long> configured{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(configured.load(std::memory_order_relaxed) & bit)) {
-        LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured.fetch_or(bit, std::memory_order_relaxed);
-    }
+    if (int rc = configure_lds_once(kern, 160 * 1024, configured)) return rc;
     kern<<<nwg, TRAIN_THREADS, lds_bytes, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
@@ -1415,28 +1478,11 @@ template <int LQ, int NL>
 static int launch_wave(const TrainArgs& A, int nwg, hipStream_t s)
 {
     auto kern = k_train_wave<LQ, NL>;
+    static std::atomic<unsigned long long> configured{0};
+    if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
     kern<<<nwg, WAVE_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
-}
-
-template <int LQ, int NL>
-static int configure_wave(const TrainPlan& p)
-{
-    LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_wave<LQ, NL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, p.wave_lds_floats * 4));
-    return 0;
-}
-
-// once per epoch call (the attribute belongs to the current device's copy of the kernel)
-static int configure_wave_kernel(const TrainPlan& p, int nl)
-{
-    switch (p.LQ) {
-        case 16: return nl == 1 ? configure_wave<16, 1>(p) : configure_wave<16, 2>(p);
-        case 32: return nl == 1 ? configure_wave<32, 1>(p) : configure_wave<32, 2>(p);
-        case 52: return nl == 1 ? configure_wave<52, 1>(p) : configure_wave<52, 2>(p);
-        default: return nl == 1 ? configure_wave<64, 1>(p) : configure_wave<64, 2>(p);
-    }
 }
 
 static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
@@ -1450,9 +1496,32 @@ static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
     }
 }
 
+template <int LQ, int NL>
+static int launch_stream(const TrainArgs& A, int nwg, hipStream_t s)
+{
+    auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD>;
+    static std::atomic<unsigned long long> configured{0};
+    if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
+    kern<<<nwg, WAVE_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
+    LBDRN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int dispatch_stream(const TrainArgs& A, int nwg, hipStream_t s)
+{
+    const bool one = A.net.nl == 1;
+    switch (A.p.LQ) {
+        case 16: return one ? launch_stream<16, 1>(A, nwg, s) : launch_stream<16, 2>(A, nwg, s);
+        case 32: return one ? launch_stream<32, 1>(A, nwg, s) : launch_stream<32, 2>(A, nwg, s);
+        case 52: return one ? launch_stream<52, 1>(A, nwg, s) : launch_stream<52, 2>(A, nwg, s);
+        default: return one ? launch_stream<64, 1>(A, nwg, s) : launch_stream<64, 2>(A, nwg, s);
+    }
+}
+
 static int dispatch_train(const TrainArgs& A, int nwg, hipStream_t s)
 {
-    if (A.p.wave) return dispatch_wave(A, nwg, s);
+    if (A.p.wave == 2) return dispatch_stream(A, nwg, s);
+    if (A.p.wave == 1) return dispatch_wave(A, nwg, s);
     switch (A.p.LQ) {
         case 16: return dispatch_nl<16>(A, nwg, s);
         case 32: return dispatch_nl<32>(A, nwg, s);
@@ -1468,9 +1537,11 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
 {
     TrainPlan p;
     size_t need = 0, off_rows = 0;
+    int LQs = 0;   // > 0: the streamed step's row order (row_source)
     if (make_train_plan(g, net, &p)) {
         const TrainWsLayout L = train_ws_layout(g, net, p, bs);
         need = L.total; off_rows = L.off_rows;
+        if (p.wave == 2) LQs = p.LQ;
     } else {
         WidePlan wp;
         if (!make_wide_plan(g, net, &wp)) {
@@ -1492,9 +1563,9 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * (size_t)std::max(net.F - 2 * g.P, 0)) * 4;
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
-        k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, msb, img, rows);
+        k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, msb, img, rows);
     } else {
-        k_build_rows<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(g, net.F, p.RP, msb, img, rows);
+        k_build_rows<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(g, net.F, p.RP, LQs, msb, img, rows);
     }
     LBDRN_LAUNCH_CHECK();
     return 0;
@@ -1539,8 +1610,6 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
     const int max_wg = (bs + TB - 1) / TB;
     LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 8 * 16 * sizeof(unsigned long long)));
 #endif
-    if (A.p.wave)
-        if (int rc = configure_wave_kernel(A.p, net.nl)) return rc;
     const int rows_per_wg = A.p.wave ? WB : TB;
     int64_t step = step0;
     int si = 0;
@@ -1584,7 +1653,12 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
             t0min = std::min(t0min, h[k * 16 + 14]);
             t1max = std::max(t1max, h[k * 16 + 15]);
         }
-        fprintf(stderr, "[lbdrn stamps, wave kernel] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
+        fprintf(stderr, A.p.wave == 2 ?
+                        "[lbdrn stamps, stream kernel] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
+                        "mean cycles: indices + first requests out %.0f | first stage landed %.0f | layer 0 under the stream %.0f | all landed, barrier %.0f | "
+                        "act0 %.0f | hidden+act %.0f | out+loss %.0f | backward %.0f | barrier 3 %.0f | dW0 strips %.0f | dW tail+hidden %.0f | "
+                        "bias sums %.0f | drain %.0f\n" :
+                        "[lbdrn stamps, wave kernel] clock %.0f MHz; wave lifetime %.0f cycles; first start -> last end %.2f us; "
                         "mean cycles: W0 DMA + rows->LDS %.0f | barrier 1 %.0f | small-matrix requests + layer0 %.0f | barrier 2 %.0f | "
                         "act0 %.0f | hidden+act %.0f | out+loss %.0f | backward %.0f | barrier 3 %.0f | dW0 strips %.0f | dW tail+hidden %.0f | "
                         "bias sums %.0f | drain %.0f\n",
