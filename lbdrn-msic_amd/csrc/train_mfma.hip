@@ -1502,7 +1502,7 @@ static int launch_stream(const TrainArgs& A, int nwg, hipStream_t s)
     auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD>;
     static std::atomic<unsigned long long> configured{0};
     if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
-    kern<<<nwg, WAVE_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
+    kern<<<nwg, STREAM_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
 }
