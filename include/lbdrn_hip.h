@@ -134,6 +134,21 @@ int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t 
                       double lr, float *losses, void *workspace, size_t workspace_bytes,
                       int32_t path, void *stream);
 
+/* The same epoch for `count` (1 .. lbdrn_train_group_max()) INDEPENDENT fits of one shape -- same raster dimensions,
+ * K, D, feature switches, network, n, batch size, Adam step count and learning rate; every array holds one entry per
+ * fit: its geometry (msb_max and tables may differ), image, MSB plane, permutation, optimiser state, losses (array or
+ * entries may be NULL) and its own prepared workspace of workspace_bytes each.  Where the shape has a fused step that
+ * takes groups, minibatch s of every fit runs in ONE launch (two 8192-row minibatches = 256 workgroups fill the
+ * chip exactly; independent chains of 128-workgroup launches meet each other only by chance), otherwise the fits
+ * run one after another.  The reference has no such call (run.sh:29-42 encodes image after image): results are those
+ * of `count` calls of lbdrn_train_epoch, bit for bit. */
+int lbdrn_train_group_max(void);
+int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom *const *g, const lbdrn_net *net,
+                            const uint16_t *const *img, const uint16_t *const *msb, const int64_t *const *perm,
+                            int64_t n, int32_t batch_size, float *const *params, float *const *exp_avg,
+                            float *const *exp_avg_sq, int64_t adam_step0, double lr, float *const *losses,
+                            void *const *workspace, size_t workspace_bytes, int32_t path, void *stream);
+
 /* DIAGNOSTIC, not part of the codec path: a measurement aid of bench.py's roofline leg, and the one piece of mutable
  * state this library keeps besides the error string -- thread-local, off (0) unless a caller sets it.  mode 1: every step of lbdrn_train_epoch on this thread
  * launches its reduce/Adam kernel twice (the second with a zero step size), mode 0: normal.  Timing one

@@ -240,6 +240,43 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int lbdrn_train_group_max(void) { return 4; }
+
+int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom* const* g, const lbdrn_net* net, const uint16_t* const* img,
+                            const uint16_t* const* msb, const int64_t* const* perm, int64_t n, int32_t batch_size,
+                            float* const* params, float* const* exp_avg, float* const* exp_avg_sq, int64_t adam_step0,
+                            double lr, float* const* losses, void* const* workspace, size_t workspace_bytes, int32_t path,
+                            void* stream)
+{
+    LBDRN_REQUIRE(count >= 1 && count <= lbdrn_train_group_max(), "group of %d fits (1..%d)", count, lbdrn_train_group_max());
+    LBDRN_REQUIRE(g && img && msb && perm && params && exp_avg && exp_avg_sq && workspace, "null pointer array");
+    if (int rc = check_net(net)) return rc;
+    for (int f = 0; f < count; ++f) {
+        LBDRN_REQUIRE(g[f] && img[f] && msb[f] && perm[f] && params[f] && exp_avg[f] && exp_avg_sq[f], "null pointer (fit %d)", f);
+        if (int rc = check_geom(g[f])) return rc;
+        if (int rc = net_matches(g[f], net)) return rc;
+        LBDRN_REQUIRE(g[f]->C == g[0]->C && g[f]->H == g[0]->H && g[f]->W == g[0]->W && g[f]->K == g[0]->K &&
+                      g[f]->D == g[0]->D && g[f]->P == g[0]->P && g[f]->use_colors == g[0]->use_colors &&
+                      g[f]->relative == g[0]->relative, "the fits of a group must have one shape (fit %d differs)", f);
+    }
+    LBDRN_REQUIRE(n >= 0 && batch_size >= 1 && adam_step0 >= 0, "bad n/batch_size/adam_step0");
+    LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
+    NEED_DEVICE();
+    // side by side on the fused step where the shape has one; otherwise (and for any shape the group launch does not
+    // take) one after another: same numbers either way
+    if (count > 1 && path != LBDRN_PATH_GENERIC && mfma_train_supported(*g[0], *net)) {
+        const int rc = mfma_train_epoch_group(count, *g[0], *net, perm, n, batch_size, params, exp_avg, exp_avg_sq,
+                                              adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
+        if (rc != LBDRN_E_UNSUPPORTED) return rc;
+    }
+    for (int f = 0; f < count; ++f)
+        if (int rc = lbdrn_train_epoch(g[f], net, img[f], msb[f], perm[f], n, batch_size, params[f], exp_avg[f],
+                                       exp_avg_sq[f], adam_step0, lr, losses ? losses[f] : nullptr, workspace[f],
+                                       workspace_bytes, path, stream))
+            return rc;
+    return 0;
+}
+
 int lbdrn_train_profile_mode(int32_t mode)
 {
     LBDRN_REQUIRE(mode == 0 || mode == 1, "mode must be 0 or 1");

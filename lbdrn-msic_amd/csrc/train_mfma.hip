@@ -47,6 +47,7 @@ namespace lbdrn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int MAX_GROUP = 4;  // independent fits of one shape that may step side by side in one launch (blockIdx.y = fit)
 constexpr int TB = 32;       // samples per workgroup
 constexpr int TBC = 64;      // hidden width this kernel is built for
 constexpr int HP = 68;       // [sample][64] rows: 17 chunks of 16 B
@@ -450,13 +451,28 @@ __global__ void __launch_bounds__(256)
 // (torch/optim/adam.py single-tensor path: lerp_, mul_/addcmul_, addcdiv_); refresh the fragment copy.
 // Block = RED_LANES float4 lanes (4*RED_LANES slab elements) x RED_SLICES workgroup slices; the final sum over
 // slices and the update are spread over 4*RED_LANES threads, one slab element each.
+struct ReduceFit {
+    const float* slabs;
+    float *params, *m, *v, *packed;
+    const double* loss_part;
+    float* loss_out;
+};
+struct ReduceArgs { ReduceFit fit[MAX_GROUP]; };
+
 __global__ void __launch_bounds__(256)
-    k_reduce_adam(const float* __restrict__ slabs, int nwg, int slab_floats, const int4* __restrict__ map,
-                  float* __restrict__ params, float* __restrict__ m, float* __restrict__ v,
-                  float* __restrict__ packed, float step_size, float bc2_sqrt,
-                  const double* __restrict__ loss_part, double loss_count, float* loss_out)
+    k_reduce_adam(ReduceArgs R, int nwg, int slab_floats, const int4* __restrict__ map, float step_size, float bc2_sqrt,
+                  double loss_count)
 {
-    __shared__ float part[RED_SLICES][4 * RED_LANES + 1];
+    // 4 KB of LDS, not a byte more: a CU that holds a training workgroup of another fit (159,744 of its 163,840 bytes)
+    // has exactly this much left, so the reduce launch of one chain runs BESIDE the training step of another instead
+    // of waiting for a CU to come free (with four fits in flight the two launches took turns: 13 ms per tile)
+    __shared__ __attribute__((aligned(16))) float part[RED_SLICES][4 * RED_LANES];
+    const ReduceFit& F = R.fit[blockIdx.y];   // the fits of a group: same shape, own state
+    const float* __restrict__ slabs = F.slabs;
+    float* __restrict__ params = F.params;
+    float* __restrict__ m = F.m;
+    float* __restrict__ v = F.v;
+    float* __restrict__ packed = F.packed;
     const int l16 = threadIdx.x % RED_LANES, slice = threadIdx.x / RED_LANES;
     const int base = blockIdx.x * (4 * RED_LANES);
     // the 32 updating threads fetch their parameter's state while the slab reads fly
@@ -483,8 +499,7 @@ __global__ void __launch_bounds__(256)
         float4 t = *reinterpret_cast<const float4*>(src + (size_t)w * slab_floats);
         acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
     }
-    part[slice][4 * l16 + 0] = acc.x; part[slice][4 * l16 + 1] = acc.y;
-    part[slice][4 * l16 + 2] = acc.z; part[slice][4 * l16 + 3] = acc.w;
+    *reinterpret_cast<float4*>(&part[slice][4 * l16]) = acc;
     __syncthreads();
     if (threadIdx.x < 4 * RED_LANES && me.x >= 0) {
         float g = part[0][threadIdx.x];
@@ -501,29 +516,34 @@ __global__ void __launch_bounds__(256)
         if (me.y >= 0) packed[me.y] = pi;
         if (me.z >= 0) packed[me.z] = pi;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && loss_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && F.loss_out) {
         double s = 0.0;
-        for (int k = 0; k < nwg; ++k) s += loss_part[k];
-        *loss_out = (float)(s / loss_count);
+        for (int k = 0; k < nwg; ++k) s += F.loss_part[k];
+        *F.loss_out = (float)(s / loss_count);
     }
 }
 
 // ------------------------------------------------------------------ the fused step
 
-struct TrainArgs {
-    lbdrn_net net;
-    TrainPlan p;
+// what differs between the fits of a group (independent fits of one shape stepping side by side in ONE launch:
+// blockIdx.y = fit; lbdrn_train_epoch_group)
+struct TrainFit {
     const float* rows;      // [N][RP] features | labels
-    int64_t npix;
     const int64_t* perm;    // this minibatch's pixel indices
-    int batch_n;            // rows in this minibatch
     const float* params;    // canonical
     const float* packed;    // fragment order
     float* slabs;           // [nwg][slab_floats]
     double* loss_part;      // [nwg]
+};
+struct TrainArgs {
+    lbdrn_net net;
+    TrainPlan p;
+    int64_t npix;
+    int batch_n;            // rows in this minibatch
     float inv;              // 1 / (batch_n * C)
-    const float* stage_in;  // [nwg][32][RP] rows of THIS minibatch, staged by the previous launch (or null)
-    float* stage_out;       // where to stage the NEXT minibatch's rows (or null)
+    TrainFit fit[MAX_GROUP];
+    const float* stage_in;  // (tile kernel) [nwg][32][RP] rows of THIS minibatch, staged by the previous launch (or null)
+    float* stage_out;       // (tile kernel) where to stage the NEXT minibatch's rows (or null)
     const int64_t* perm_next;
     int next_n;
     unsigned long long* stamps;  // diagnostic build only (-DLBDRN_TRAIN_STAMPS): [nwg][16] s_memtime
@@ -585,6 +605,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const TrainPlan& p = A.p;
+    const TrainFit& Ft = A.fit[0];
     const int tid = threadIdx.x, lane = tid & 63, w8 = tid >> 6;
     const int w = w8 & 3, st = w8 >> 2;
     const int i = lane & 15, q = lane >> 4;
@@ -604,7 +625,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     const int first = wg * TB;
     const int nvalid = min(TB, A.batch_n - first);
     const int srow = i + 16 * st;  // the sample (row of X / H / dZ) this lane's B operands come from
-    float* slab = A.slabs + (size_t)wg * p.slab_floats;
+    float* slab = Ft.slabs + (size_t)wg * p.slab_floats;
     const WtBuf slabw(slab, (size_t)p.slab_floats * 4);
 #ifdef LBDRN_TRAIN_STAMPS
     unsigned long long stamp[16] = {};
@@ -620,7 +641,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     // gathers for itself.
     const bool staged = A.stage_in != nullptr;
     int64_t mypix = 0;
-    if (!staged && tid < TB) mypix = A.perm[first + min(tid, nvalid - 1)];
+    if (!staged && tid < TB) mypix = Ft.perm[first + min(tid, nvalid - 1)];
     const int rs = tid >> 4, rsub = tid & 15;  // row copy: 16 threads per row
     constexpr int NLD = (XP / 4 + 15) / 16;
     const int rp4 = p.RP >> 2;
@@ -640,7 +661,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     // ---- weight prefetch: everything this wave will multiply by, L2 -> VGPR, before the gather
     float a0[LQ];
     {
-        const float4* wf0 = reinterpret_cast<const float4*>(A.packed + p.pk_w0) + (size_t)w * (LQ / 4) * 64 + lane;
+        const float4* wf0 = reinterpret_cast<const float4*>(Ft.packed + p.pk_w0) + (size_t)w * (LQ / 4) * 64 + lane;
 #pragma unroll
         for (int g = 0; g < LQ / 4; ++g) {
             const float4 t = wf0[g * 64];
@@ -650,7 +671,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     float ah[NL > 1 ? NL - 1 : 1][16];
 #pragma unroll
     for (int l = 1; l < NL; ++l) {
-        const float4* wfh = reinterpret_cast<const float4*>(A.packed + p.pk_wh) + (size_t)((l - 1) * 4 + w) * 4 * 64 + lane;
+        const float4* wfh = reinterpret_cast<const float4*>(Ft.packed + p.pk_wh) + (size_t)((l - 1) * 4 + w) * 4 * 64 + lane;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 t = wfh[g * 64];
@@ -659,7 +680,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
     }
     float al[16];
     {
-        const float4* wfl = reinterpret_cast<const float4*>(A.packed + p.pk_wl) + lane;
+        const float4* wfl = reinterpret_cast<const float4*>(Ft.packed + p.pk_wl) + lane;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 t = wfl[g * 64];
@@ -670,22 +691,22 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         int ch = 4 * q + s;
-        atl[s] = ch < C ? A.params[p.offW[NL] + (int64_t)ch * TBC + 16 * w + i] : 0.0f;
+        atl[s] = ch < C ? Ft.params[p.offW[NL] + (int64_t)ch * TBC + 16 * w + i] : 0.0f;
     }
     float ath[NL > 1 ? NL - 1 : 1][16];  // W_l^T: A[i = in 16w+i][k = out 16q+s]
 #pragma unroll
     for (int l = 1; l < NL; ++l)
 #pragma unroll
-        for (int s = 0; s < 16; ++s) ath[l - 1][s] = A.params[p.offW[l] + (int64_t)(16 * q + s) * TBC + 16 * w + i];
+        for (int s = 0; s < 16; ++s) ath[l - 1][s] = Ft.params[p.offW[l] + (int64_t)(16 * q + s) * TBC + 16 * w + i];
     f32x4 bias[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        float4 b4 = *reinterpret_cast<const float4*>(A.params + p.offB[l] + 16 * w + 4 * q);
+        float4 b4 = *reinterpret_cast<const float4*>(Ft.params + p.offB[l] + 16 * w + 4 * q);
         bias[l][0] = b4.x; bias[l][1] = b4.y; bias[l][2] = b4.z; bias[l][3] = b4.w;
     }
     f32x4 bias_last;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? A.params[p.offB[NL] + 4 * q + r] : 0.0f;
+    for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? Ft.params[p.offB[NL] + 4 * q + r] : 0.0f;
 
     // ---- phase 0: which rows
     if (!staged) {
@@ -705,14 +726,14 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
         float* xr = Xs + s * XP;
         const int nt16 = 16 * p.NT0;
         if (!staged) {  // first step of an epoch: gather for itself
-            const float* src = A.rows + (size_t)pixs[s] * p.RP;
+            const float* src = Ft.rows + (size_t)pixs[s] * p.RP;
 #pragma unroll
             for (int u = 0; u < NLD; ++u) v[u] = *reinterpret_cast<const float4*>(src + 4 * min(sub + 16 * u, rp4 - 1));
         }
         // the next minibatch's rows: issued now, consumed at the very end of the kernel
         {
             const int64_t np = nextpix < 0 ? 0 : (nextpix >= A.npix ? A.npix - 1 : nextpix);
-            const float* nsrc = A.rows + (size_t)np * p.RP;
+            const float* nsrc = Ft.rows + (size_t)np * p.RP;
 #pragma unroll
             for (int u = 0; u < NLD; ++u) vnext[u] = *reinterpret_cast<const float4*>(nsrc + 4 * min(sub + 16 * u, rp4 - 1));
         }
@@ -805,7 +826,7 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
         if (lane == 0) red[st] = lsum;
     }
     __syncthreads();
-    if (tid == 0) A.loss_part[wg] = red[0] + red[1];
+    if (tid == 0) Ft.loss_part[wg] = red[0] + red[1];
     STAMP(6);
     // (the loads were issued ~8 k cycles ago; storing here, write-through, lets them drain under the backward pass)
     if (nextpix >= 0) {  // park the next minibatch's rows (loaded at kernel start) in the staging buffer
@@ -994,6 +1015,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const TrainPlan& p = A.p;
+    const TrainFit& Ft = A.fit[0];
     constexpr int XP = wave_xp(LQ), HP = WHP, OP = WOP, PT = WPT, G0 = LQ / 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler should know it
@@ -1011,7 +1033,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     const int wg = blockIdx.x, first = wg * WB;
     const int nvalid = min(WB, A.batch_n - first);
     const int srow = 16 * w + i;            // this lane's sample (column of every forward / backward tile)
-    float* slab = A.slabs + (size_t)wg * p.slab_floats;
+    float* slab = Ft.slabs + (size_t)wg * p.slab_floats;
     const WtBuf slabw(slab, (size_t)p.slab_floats * 4);
 #ifdef LBDRN_TRAIN_STAMPS
     unsigned long long stamp[16] = {};
@@ -1024,19 +1046,19 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     // (rows past the end repeat the last row: finite values; the raw index is clamped where it is used, so that
     //  nothing here waits for the load)
     auto clamp_pix = [&](int64_t pix) -> int { return (int)(pix < 0 ? 0 : (pix >= A.npix ? A.npix - 1 : pix)); };
-    const int64_t raw_mine = A.stage_in == nullptr ? A.perm[min(first + 16 * w + i, A.batch_n - 1)] : 0;
+    const int64_t raw_mine = A.stage_in == nullptr ? Ft.perm[min(first + 16 * w + i, A.batch_n - 1)] : 0;
     // biases: tiny, and the first MFMA of every layer starts from them -- ahead of every other request
     f32x4 bias[NL][4];
 #pragma unroll
     for (int l = 0; l < NL; ++l)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const float4 b4 = *reinterpret_cast<const float4*>(A.params + p.offB[l] + 16 * t + 4 * q);
+            const float4 b4 = *reinterpret_cast<const float4*>(Ft.params + p.offB[l] + 16 * t + 4 * q);
             bias[l][t][0] = b4.x; bias[l][t][1] = b4.y; bias[l][t][2] = b4.z; bias[l][t][3] = b4.w;
         }
     f32x4 bias_last;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? A.params[p.offB[NL] + 4 * q + r] : 0.0f;
+    for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? Ft.params[p.offB[NL] + 4 * q + r] : 0.0f;
 
     // ---- rows: the wave copies its own 16 rows (16 * RP/4 chunks of 16 B, chunk c = lane + 64 u), gathered from the
     //      [N][RP] row matrix by pixel index (a staging buffer filled one launch ahead, as the tile kernel keeps, buys
@@ -1064,7 +1086,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
             int row = row0, col = col0;
 #pragma unroll
             for (int u = 0; u < NLD; ++u) {
-                srcs[u] = A.rows + (size_t)__shfl(pix_mine, min(row, 15)) * p.RP + 4 * col;
+                srcs[u] = Ft.rows + (size_t)__shfl(pix_mine, min(row, 15)) * p.RP + 4 * col;
                 row += p.w_dp; col += p.w_df;
                 if (col >= rp4) { col -= rp4; row += 1; }
             }
@@ -1075,7 +1097,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     }
     // ---- layer-0 fragments -> LDS, this wave's quarter (tile w: G0 blocks of 1 KB, contiguous in the packed copy)
     {
-        const float* src = A.packed + p.pk_w0 + (size_t)w * G0 * 256 + lane * 4;
+        const float* src = Ft.packed + p.pk_w0 + (size_t)w * G0 * 256 + lane * 4;
         float* dst = R + w * G0 * 256;
 #pragma unroll
         for (int g = 0; g < G0; ++g) LBDRN_LDS_DMA(src + g * 256, dst + g * 256);
@@ -1088,7 +1110,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     // ---- every other request of the step rides inside layer 0, a few per group of 16 MFMAs, where the vector-memory
     //      path is otherwise idle (a burst of them stalls the wave: the path takes 64 B/clk per CU): the small matrices
     //      of the following products (L2 -> VGPR, fragment order), then the transposed ones of the backward products.
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A.packed), (short)0,
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ft.packed), (short)0,
                                                                          p.pack_floats * 4, 0x00020000);
     const int lane16 = lane * 16;
     auto ldw = [&](int float_base, int block) -> float4 {
@@ -1276,7 +1298,7 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
     }
     STAMP(8);
     __syncthreads();
-    if (tid == 0) A.loss_part[wg] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
+    if (tid == 0) Ft.loss_part[wg] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
     STAMP(9);
 
     // ---- weight gradients: K = the 64 samples (16 steps; lane quarter q, step j = sample 4 j + q).
@@ -1497,30 +1519,30 @@ static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
 }
 
 template <int LQ, int NL>
-static int launch_stream(const TrainArgs& A, int nwg, hipStream_t s)
+static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
     auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD>;
     static std::atomic<unsigned long long> configured{0};
     if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
-    kern<<<nwg, STREAM_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
+    kern<<<dim3((unsigned)nwg, (unsigned)count), STREAM_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
 }
 
-static int dispatch_stream(const TrainArgs& A, int nwg, hipStream_t s)
+static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
     const bool one = A.net.nl == 1;
     switch (A.p.LQ) {
-        case 16: return one ? launch_stream<16, 1>(A, nwg, s) : launch_stream<16, 2>(A, nwg, s);
-        case 32: return one ? launch_stream<32, 1>(A, nwg, s) : launch_stream<32, 2>(A, nwg, s);
-        case 52: return one ? launch_stream<52, 1>(A, nwg, s) : launch_stream<52, 2>(A, nwg, s);
-        default: return one ? launch_stream<64, 1>(A, nwg, s) : launch_stream<64, 2>(A, nwg, s);
+        case 16: return one ? launch_stream<16, 1>(A, nwg, count, s) : launch_stream<16, 2>(A, nwg, count, s);
+        case 32: return one ? launch_stream<32, 1>(A, nwg, count, s) : launch_stream<32, 2>(A, nwg, count, s);
+        case 52: return one ? launch_stream<52, 1>(A, nwg, count, s) : launch_stream<52, 2>(A, nwg, count, s);
+        default: return one ? launch_stream<64, 1>(A, nwg, count, s) : launch_stream<64, 2>(A, nwg, count, s);
     }
 }
 
-static int dispatch_train(const TrainArgs& A, int nwg, hipStream_t s)
+static int dispatch_train(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
-    if (A.p.wave == 2) return dispatch_stream(A, nwg, s);
+    if (A.p.wave == 2) return dispatch_stream(A, nwg, count, s);
     if (A.p.wave == 1) return dispatch_wave(A, nwg, s);
     switch (A.p.LQ) {
         case 16: return dispatch_nl<16>(A, nwg, s);
@@ -1579,68 +1601,95 @@ int train_profile_mode(int mode)
     return 0;
 }
 
-int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
-                     const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
-                     float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
-                     size_t ws_bytes, hipStream_t s)
+// One epoch of `count` fits of one shape, stepping side by side (count == 1: the plain call).  Groups of more than
+// one fit run on the streamed step only: minibatch s of every fit is ONE launch of count x nwg workgroups
+// (blockIdx.y = fit) and one reduce launch -- two fits fill the chip's 256 CUs exactly, instead of two 128-workgroup
+// launches of independent chains meeting each other by chance.  Every fit keeps its own workspace, state and slabs:
+// the numbers are those of `count` separate calls, bit for bit.
+int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net, const int64_t* const* perm, int64_t n,
+                           int bs, float* const* params, float* const* m, float* const* v, int64_t step0, double lr,
+                           float* const* losses, void* const* ws, size_t ws_bytes, hipStream_t s)
 {
     TrainArgs A;
-    if (!make_train_plan(g, net, &A.p))
-        return wide_train_epoch(g, net, perm, n, bs, params, m, v, step0, lr, losses, ws, ws_bytes, s);
+    if (!make_train_plan(g, net, &A.p)) {
+        if (count != 1) { set_error("groups of fits run on the bc = 64 fused step only"); return LBDRN_E_UNSUPPORTED; }
+        return wide_train_epoch(g, net, perm[0], n, bs, params[0], m[0], v[0], step0, lr, losses ? losses[0] : nullptr,
+                                ws[0], ws_bytes, s);
+    }
+    if (count < 1 || count > MAX_GROUP || (count > 1 && A.p.wave != 2)) {
+        set_error("a group of %d fits is not supported by this shape's train kernel", count);
+        return LBDRN_E_UNSUPPORTED;
+    }
     const TrainWsLayout L = train_ws_layout(g, net, A.p, bs);
-    if (!ws || ws_bytes < L.total) {
+    if (ws_bytes < L.total) {
         set_error("train workspace too small: %zu < %zu", ws_bytes, L.total);
         return LBDRN_E_WORKSPACE;
     }
-    float* rows = (float*)((char*)ws + L.off_rows);
-    float* packed = (float*)((char*)ws + L.off_pack);
-    float* slabs = (float*)((char*)ws + L.off_slab);
-    double* loss_part = (double*)((char*)ws + L.off_loss);
-    LBDRN_HIP_TRY(hipMemsetAsync(packed, 0, (size_t)A.p.pack_floats * sizeof(float), s));
-    k_pack_train<<<(unsigned)((A.p.NP + 255) / 256), 256, 0, s>>>(params, A.p, net.F, net.nl, net.C, packed);
-    LBDRN_LAUNCH_CHECK();
-    A.net = net; A.rows = rows; A.npix = (int64_t)g.H * g.W; A.params = params; A.packed = packed;
-    A.slabs = slabs; A.loss_part = loss_part;
-    int4* map = (int4*)((char*)ws + L.off_map);
+    A.net = net; A.npix = (int64_t)g.H * g.W;
+    ReduceArgs R;
+    for (int f = 0; f < MAX_GROUP; ++f) {
+        const int k = f < count ? f : 0;   // (unused slots repeat fit 0: never read)
+        if (!ws[k]) { set_error("null train workspace"); return LBDRN_E_WORKSPACE; }
+        float* packed = (float*)((char*)ws[k] + L.off_pack);
+        A.fit[f].rows = (float*)((char*)ws[k] + L.off_rows);
+        A.fit[f].params = params[k];
+        A.fit[f].packed = packed;
+        A.fit[f].slabs = (float*)((char*)ws[k] + L.off_slab);
+        A.fit[f].loss_part = (double*)((char*)ws[k] + L.off_loss);
+        A.fit[f].perm = perm[k];
+        R.fit[f].slabs = A.fit[f].slabs; R.fit[f].params = params[k]; R.fit[f].m = m[k]; R.fit[f].v = v[k];
+        R.fit[f].packed = packed; R.fit[f].loss_part = A.fit[f].loss_part; R.fit[f].loss_out = nullptr;
+        if (f < count) {
+            LBDRN_HIP_TRY(hipMemsetAsync(packed, 0, (size_t)A.p.pack_floats * sizeof(float), s));
+            k_pack_train<<<(unsigned)((A.p.NP + 255) / 256), 256, 0, s>>>(params[k], A.p, net.F, net.nl, net.C, packed);
+            LBDRN_LAUNCH_CHECK();
+        }
+    }
+    int4* map = (int4*)((char*)ws[0] + L.off_map);   // slab element -> parameter: a function of the shape only
     k_build_map<<<(unsigned)((A.p.slab_floats + 255) / 256), 256, 0, s>>>(A.p, net.F, net.nl, net.C, map);
     LBDRN_LAUNCH_CHECK();
-    float* stage[2] = {(float*)((char*)ws + L.off_stage), (float*)((char*)ws + L.off_stage + L.stage_bytes)};
+    float* stage[2] = {(float*)((char*)ws[0] + L.off_stage), (float*)((char*)ws[0] + L.off_stage + L.stage_bytes)};
     A.stamps = nullptr;
 #ifdef LBDRN_TRAIN_STAMPS
     const int max_wg = (bs + TB - 1) / TB;
     LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 8 * 16 * sizeof(unsigned long long)));
 #endif
     const int rows_per_wg = A.p.wave ? WB : TB;
+    const dim3 red_grid((unsigned)(A.p.slab_floats / (4 * RED_LANES)), (unsigned)count);
     int64_t step = step0;
     int si = 0;
     for (int64_t first = 0; first < n; first += bs, ++si) {
         const int B = (int)std::min<int64_t>(bs, n - first);
         const int nwg = (B + rows_per_wg - 1) / rows_per_wg;
-        A.perm = perm + first;
+        for (int f = 0; f < MAX_GROUP; ++f) {
+            const int k = f < count ? f : 0;
+            A.fit[f].perm = perm[k] + first;
+            R.fit[f].loss_out = (f < count && losses && losses[k]) ? losses[k] + si : nullptr;
+        }
         A.batch_n = B;
         A.inv = 1.0f / ((float)B * (float)net.C);
         const int64_t nextB = std::max<int64_t>(0, std::min<int64_t>(bs, n - first - bs));
         A.stage_in = si > 0 ? stage[si & 1] : nullptr;          // staged by the previous launch
         A.stage_out = nextB > 0 ? stage[(si + 1) & 1] : nullptr;
-        if (A.p.wave) A.stage_in = nullptr, A.stage_out = nullptr;   // the wave-local kernel gathers for itself
-        A.perm_next = perm + first + bs;
+        if (A.p.wave) A.stage_in = nullptr, A.stage_out = nullptr;   // the wave-local kernels gather for themselves
+        A.perm_next = perm[0] + first + bs;
         A.next_n = (int)nextB;
-        if (int rc = dispatch_train(A, nwg, s)) return rc;
+        if (int rc = dispatch_train(A, nwg, count, s)) return rc;
         ++step;
         const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
-        k_reduce_adam<<<(unsigned)(A.p.slab_floats / (4 * RED_LANES)), 256, 0, s>>>(
-            slabs, nwg, A.p.slab_floats, map, params, m, v, packed, (float)(lr / bc1), (float)std::sqrt(bc2),
-            loss_part, (double)B * net.C, losses ? losses + si : nullptr);
-        if (g_prof_mode == 1)  // measurement only: the same launch again with a zero step
-            k_reduce_adam<<<(unsigned)(A.p.slab_floats / (4 * RED_LANES)), 256, 0, s>>>(
-                slabs, nwg, A.p.slab_floats, map, params, m, v, packed, 0.0f, (float)std::sqrt(bc2), loss_part,
-                (double)B * net.C, nullptr);
+        k_reduce_adam<<<red_grid, 256, 0, s>>>(R, nwg, A.p.slab_floats, map, (float)(lr / bc1), (float)std::sqrt(bc2),
+                                               (double)B * net.C);
+        if (g_prof_mode == 1) {  // measurement only: the same launch again with a zero step
+            ReduceArgs R0 = R;
+            for (int f = 0; f < MAX_GROUP; ++f) R0.fit[f].loss_out = nullptr;
+            k_reduce_adam<<<red_grid, 256, 0, s>>>(R0, nwg, A.p.slab_floats, map, 0.0f, (float)std::sqrt(bc2), (double)B * net.C);
+        }
         LBDRN_LAUNCH_CHECK();
     }
 #ifdef LBDRN_TRAIN_STAMPS
     if (A.p.wave) {   // diagnostic: mean cycles per phase over the waves of the last step
         LBDRN_HIP_TRY(hipStreamSynchronize(s));
-        const int nw = ((int)std::min<int64_t>(bs, n) + rows_per_wg - 1) / rows_per_wg * 4;
+        const int nw = ((int)std::min<int64_t>(bs, n) + rows_per_wg - 1) / rows_per_wg * 4 * (A.p.wave == 2 ? count : 1);
         std::vector<unsigned long long> h((size_t)nw * 16);
         LBDRN_HIP_TRY(hipMemcpy(h.data(), A.stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         (void)hipFree(A.stamps);
@@ -1685,6 +1734,14 @@ int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* 
     }
 #endif
     return 0;
+}
+
+int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
+                     const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
+                     float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
+                     size_t ws_bytes, hipStream_t s)
+{
+    return mfma_train_epoch_group(1, g, net, &perm, n, bs, &params, &m, &v, step0, lr, &losses, &ws, ws_bytes, s);
 }
 
 }  // namespace lbdrn

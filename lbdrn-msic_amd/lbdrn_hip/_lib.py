@@ -51,6 +51,9 @@ SIGNATURES = {
     "lbdrn_train_prepare": (ctypes.c_int, [_GP, _NP, _vp, _vp, _i32, _vp, _sz, _i32, _vp]),
     "lbdrn_train_epoch": (ctypes.c_int, [_GP, _NP, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64,
                                          _dbl, _vp, _vp, _sz, _i32, _vp]),
+    "lbdrn_train_group_max": (ctypes.c_int, []),
+    "lbdrn_train_epoch_group": (ctypes.c_int, [_i32, _vp, _NP, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _dbl, _vp,
+                                               _vp, _sz, _i32, _vp]),
     "lbdrn_train_profile_mode": (ctypes.c_int, [_i32]),
     "lbdrn_randperm_workspace": (_sz, [_i64, _i32]),
     "lbdrn_randperm": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), _i32, _i64, _vp, _vp, _sz, _vp]),

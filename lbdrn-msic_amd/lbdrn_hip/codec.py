@@ -221,21 +221,107 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     return out
 
 
-def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
-             path=ops.PATH_AUTO, seed=19920517, in_flight=None, then=None, draws=None):
-    """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time, each on
-    its own stream and host thread (in_flight=None: 4); returns [then(fit) or fit, ...] in input order.
+def fit_group(imgs_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
+              path=ops.PATH_AUTO, keep_losses=False, seed=None, draws=None):
+    """Several independent fits of ONE raster shape, stepping side by side on the calling thread's stream: every
+    minibatch of the group is one launch (ops.train_epoch_group) -- two 8192-row minibatches are 256 workgroups,
+    the whole chip, where two independent chains of 128-workgroup launches only meet by chance.  Each fit is exactly
+    fit_device()'s fit (same draws, same kernels per fit, own workspace and state): the results are bit-identical to
+    fitting the images one after another.  `seed`: every fit seeds the generator itself (independent images, one
+    encode.py invocation each); `draws`: one FitDraws per image.  Returns one DeviceFit per image."""
+    cfg = cfg or FeatCfg.from_constants()
+    G = len(imgs_d)
+    dev = imgs_d[0].device
+    C, H, W = imgs_d[0].shape
+    if any(tuple(t.shape) != (C, H, W) for t in imgs_d):
+        raise ValueError("the fits of a group must have one raster shape")
+    N = H * W
+    if N >= GPU_RANDPERM_MAX:
+        raise ops._lib.LbdrnError(f"{N} pixels in one fit: split the image (-sr)")
+    outs = [DeviceFit() for _ in range(G)]
+    st = []
+    net = None
+    for k, img_d in enumerate(imgs_d):
+        msb_d, msb_max = ops.split_bits(img_d, K)            # a1
+        geom = ops.FeatureGeometry(C, H, W, K, D, msb_max, cfg, dev)
+        dr = draws[k] if draws is not None else None
+        if dr is None:
+            with _RNG_LOCK:
+                if seed is not None:
+                    torch.manual_seed(seed)
+                dr = draw_fit(geom.F, base_channel, C, num_layers, epochs, val_duration)
+        net = ops.make_net(geom.F, base_channel, C, num_layers)
+        params = dr.params.to(dev).contiguous()
+        if params.numel() != ops.param_count(net):
+            raise ValueError("draws were made for another network shape")
+        steps = (N + batch_size - 1) // batch_size
+        st.append(dict(
+            img=img_d, msb=msb_d, msb_max=msb_max, geom=geom, params=params, params0=params.clone(),
+            m=torch.zeros_like(params), v=torch.zeros_like(params),
+            perms=DevicePermutationStream(N, epochs, val_duration, dev, train_seeds=dr.train_seeds),
+            losses=torch.zeros((epochs, steps), dtype=torch.float32, device=dev) if keep_losses else None,
+            tws=ops.TrainWorkspace(geom, net, batch_size, dev).prepare(img_d, msb_d, path),   # a2-a4
+            aws=ops.ApplyWorkspace(geom, net, dev)))
+    lrs = lr_schedule(lr, epochs)
+    steps_per_epoch = (N + batch_size - 1) // batch_size
+    eval_epochs = [] if epochs == 1 else [e for e in range(1, epochs + 1) if e % min(val_duration, epochs) == 0]
+    for f in st:
+        f["snaps"] = torch.empty((max(len(eval_epochs), 1), f["params"].numel()), dtype=torch.float32, device=dev)
+        f["mses"] = torch.zeros((max(len(eval_epochs), 1),), dtype=torch.float32, device=dev)
+    adam_steps = 0
+    for e in range(1, epochs + 1):
+        perms = [f["perms"].get(e).to(dev, non_blocking=True) for f in st]          # a4
+        ops.train_epoch_group([f["geom"] for f in st], net, [f["img"] for f in st], [f["msb"] for f in st], perms,
+                              batch_size, [f["params"] for f in st], [f["m"] for f in st], [f["v"] for f in st],
+                              adam_steps, lrs[e - 1], [f["losses"][e - 1] for f in st] if keep_losses else None,
+                              path, [f["tws"] for f in st])
+        adam_steps += steps_per_epoch
+        if e in eval_epochs:                                                          # encode.py:104-117
+            k = eval_epochs.index(e)
+            for f, out in zip(st, outs):
+                f["snaps"][k].copy_(f["params"])
+                sse = ops.eval_sse(f["geom"], net, f["img"], f["msb"], f["snaps"][k], path, f["aws"])   # a9
+                f["mses"][k:k + 1].copy_((sse / float(N * C)).float())
+                out.evaluated.append(e)
+    for f, out in zip(st, outs):
+        best_params = f["params"].clone() if epochs == 1 else f["params0"]      # encode.py:100-103 / :91
+        best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)       # encode.py:91
+        mse_log = torch.zeros((epochs, 2), dtype=torch.float32, device=dev)
+        for k, e in enumerate(eval_epochs):
+            mse = f["mses"][k:k + 1]
+            improved = mse < best_mse
+            best_params = torch.where(improved, f["snaps"][k], best_params)
+            best_mse = torch.where(improved, mse, best_mse)
+            mse_log[e - 1, 0] = mse[0]
+            mse_log[e - 1, 1] = improved[0].float()
+        f["perms"].close()
+        out.best_params, out.msb, out.msb_max, out.geom, out.net = best_params, f["msb"], f["msb_max"], f["geom"], net
+        out.mse_log, out.losses, out.epochs = mse_log, f["losses"], epochs
+    return outs
 
-    Why: one fit is a strict chain of short dependent kernels (train 19 us on half the chip -> reduce/Adam 5 us
-    -> train ...); independent chains side by side fill the other half and the holes (measured per 8 x 2048^2
-    tile: 137 ms alone, 92 with two, 77 with four in flight; more adds nothing).  Images are independent
-    fits and every fit seeds the generator itself (`seed`, what each encode.py invocation does,
-    ref encode.py:200-205), so results are bit-identical to fitting them one after another.
+
+def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
+             path=ops.PATH_AUTO, seed=19920517, in_flight=None, then=None, draws=None, group=None):
+    """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time (None: 4); returns
+    [then(fit) or fit, ...] in input order.
+
+    Why: one fit is a strict chain of short dependent kernels (train step ~16 us on half the chip -> reduce/Adam
+    ~5 us -> train ...), so several independent fits progress together.  How they share the chip is `group`:
+    fits of one raster shape are taken `group` at a time and step side by side in ONE launch per minibatch
+    (fit_group: 2 x 128 workgroups = every CU, deterministically), and in_flight // group such groups run on their
+    own streams and host threads, one training while the other reduces.  group=None: LBDRN_FIT_GROUP, else 2 when at
+    least four fits are in flight, else 1 (every fit its own chain: round 2's scheme, 128-workgroup launches of
+    independent chains that pair up on the chip only by chance).  Images are independent fits and
+    every fit seeds the generator itself (`seed`, what each encode.py invocation does, ref encode.py:200-205), so
+    results are bit-identical to fitting them one after another, whatever the grouping.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
     coding, ...).  `draws`: one FitDraws per image instead of `seed` (the tiles of one image, whose draws the
     caller made in tile order).  Returns after all streams have been joined to the caller's current stream."""
     if in_flight is None:
         in_flight = 4
+    if group is None:
+        group = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (2 if in_flight >= 4 else 1)
+    group = max(1, min(group, in_flight, ops.train_group_max()))
     if draws is not None:
         seed = None
         if len(draws) != len(images):
@@ -248,36 +334,51 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     taken = []   # worker index -> stream of the process-wide pool
 
     def work(job):
-        img_d, dr = job
+        idx, imgs, drs = job
         if not hasattr(local, "stream"):
             # streams are kept for the life of the process: torch's caching allocator pools memory per stream,
             # so a fresh stream per call would send every fit's 3.5 GB workspace back to hipMalloc
             with _POOL_LOCK:
                 k = len(taken)
                 taken.append(None)
-            local.stream = _fit_stream_pool(img_d.device, k + 1)[k]
+            local.stream = _fit_stream_pool(imgs[0].device, k + 1)[k]
             local.stream.wait_stream(caller)
         with torch.cuda.stream(local.stream):
-            fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
-                             path, seed=seed, draws=dr, alone=False)
-            out = then(fit) if then is not None else fit
+            if len(imgs) == 1:
+                fits = [fit_device(imgs[0], K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg,
+                                   path, seed=seed, draws=drs[0], alone=False)]
+            else:
+                fits = fit_group(imgs, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg, path,
+                                 seed=seed, draws=drs if draws is not None else None)
+            outs = [then(fit) if then is not None else fit for fit in fits]
             done = torch.cuda.Event()
             done.record(local.stream)
-        return out, done
+        return idx, outs, done
 
-    jobs = list(zip(images, draws if draws is not None else [None] * len(images)))
+    drs_all = draws if draws is not None else [None] * len(images)
     if in_flight <= 1 or len(images) <= 1:
         results = []
-        for img_d, dr in jobs:
+        for img_d, dr in zip(images, drs_all):
             fit = fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration, cfg, path,
                              seed=seed, draws=dr)
             results.append(then(fit) if then is not None else fit)
         return results
-    with ThreadPoolExecutor(max_workers=in_flight) as pool:
-        pairs = list(pool.map(work, jobs))
-    for _, done in pairs:
+    # consecutive images of one shape, `group` at a time
+    jobs, k = [], 0
+    while k < len(images):
+        n = 1
+        while n < group and k + n < len(images) and tuple(images[k + n].shape) == tuple(images[k].shape):
+            n += 1
+        jobs.append((list(range(k, k + n)), list(images[k:k + n]), list(drs_all[k:k + n])))
+        k += n
+    with ThreadPoolExecutor(max_workers=max(1, in_flight // group)) as pool:
+        done_jobs = list(pool.map(work, jobs))
+    results = [None] * len(images)
+    for idx, outs, done in done_jobs:
         caller.wait_event(done)
-    return [out for out, _ in pairs]
+        for i, o in zip(idx, outs):
+            results[i] = o
+    return results
 
 
 def truncate_device(params, precision):

@@ -191,6 +191,36 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
                                   ws.nbytes, path)
 
 
+def train_group_max():
+    return int(lib().lbdrn_train_group_max())
+
+
+def train_epoch_group(geoms, net, imgs, msbs, perms, batch_size, params, exp_avgs, exp_avg_sqs, adam_step0, lr,
+                      losses=None, path=PATH_AUTO, wss=None):
+    """train_epoch for several independent fits of ONE shape, stepping side by side (lbdrn_train_epoch_group: one
+    launch per minibatch for the whole group where the fused step takes groups).  Lists, one entry per fit; every
+    workspace prepared for its image.  Same numbers as one train_epoch call per fit."""
+    n = len(imgs)
+    _need_cuda(*imgs, *msbs, *perms, *params, *exp_avgs, *exp_avg_sqs)
+    imgs = [_u16(t.contiguous()) for t in imgs]
+    msbs = [_u16(t.contiguous()) for t in msbs]
+    for t in perms:
+        assert t.dtype == torch.int64 and t.is_contiguous() and t.numel() == perms[0].numel()
+    for t in list(params) + list(exp_avgs) + list(exp_avg_sqs):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    for ws, img in zip(wss, imgs):
+        if ws.prepared_for != (img.data_ptr(), path) or ws.nbytes != wss[0].nbytes:
+            raise _lib.LbdrnError("every fit of a group needs its own TrainWorkspace, prepared for its image")
+    arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+    garr = (ctypes.POINTER(Geom) * n)(*[ctypes.pointer(g.c) for g in geoms])
+    larr = arr([_ptr(t) for t in losses]) if losses is not None else None
+    _call(lib().lbdrn_train_epoch_group, imgs[0], n, ctypes.cast(garr, ctypes.c_void_p), ctypes.byref(net),
+          arr([_ptr(t) for t in imgs]), arr([_ptr(t) for t in msbs]), arr([_ptr(t) for t in perms]),
+          perms[0].numel(), batch_size, arr([_ptr(t) for t in params]), arr([_ptr(t) for t in exp_avgs]),
+          arr([_ptr(t) for t in exp_avg_sqs]), adam_step0, float(lr), larr, arr([_ptr(w.buf) for w in wss]),
+          wss[0].nbytes, path)
+
+
 def train_profile_mode(mode):
     """Measurement aid: mode 1 makes train_epoch launch every reduce/Adam kernel twice (see lbdrn_hip.h)."""
     check(lib().lbdrn_train_profile_mode(int(mode)))

@@ -437,6 +437,35 @@ def test_fits_in_flight_together_equal_fits_one_by_one(dev):
         codec.fit_many(imgs, *args, seed=None, in_flight=2)
 
 
+def test_fits_of_a_group_step_side_by_side_and_equal_fits_one_by_one(dev):
+    """codec.fit_group / lbdrn_train_epoch_group: independent fits of one raster shape whose minibatches run in ONE
+    launch (blockIdx.y = fit) give, bit for bit, what each gives alone -- also with a ragged last minibatch, with three
+    fits in the group, through fit_many's automatic grouping (in_flight = 4), and with the per-step losses kept."""
+    shape = (8, 70, 90)                              # 6300 pixels: 24 full minibatches of 256 + one of 156
+    imgs = [ops.to_device_u16(synthetic_tile(40 + i, *shape), dev) for i in range(5)]
+    other = ops.to_device_u16(synthetic_tile(50, 4, 64, 64), dev)
+    args = (5, 2, 64, 2, 1e-3, 256, 3)
+    alone = []
+    for img_d in imgs + [other]:
+        torch.manual_seed(19920517)
+        alone.append(codec.fit_device(img_d, *args, keep_losses=True))
+    same = lambda a, b: (torch.equal(a.best_params.view(torch.int32), b.best_params.view(torch.int32)) and
+                         torch.equal(a.mse_log, b.mse_log))
+    for n in (2, 3):
+        grouped = codec.fit_group(imgs[:n], *args, seed=19920517, keep_losses=True)
+        torch.cuda.synchronize()
+        for a, b in zip(alone, grouped):
+            assert same(a, b)
+            assert torch.equal(a.losses, b.losses)
+    # fit_many: pairs of equal shape step together, the odd one out (another shape) and the leftover run alone
+    together = codec.fit_many(imgs[:3] + [other] + imgs[3:], *args, seed=19920517, in_flight=4)
+    torch.cuda.synchronize()
+    for a, b in zip(alone[:3] + [alone[5]] + alone[3:5], together):
+        assert same(a, b)
+    with pytest.raises(ValueError):
+        codec.fit_group([imgs[0], other], *args, seed=19920517)
+
+
 def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     """bench.py on a small tile (same code path as the full-size run): exactly one JSON line on stdout with the
     driver's keys, the roofline and cpu_baseline objects, and values of the right kind."""
