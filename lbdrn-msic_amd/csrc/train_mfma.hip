@@ -289,12 +289,14 @@ __global__ void __launch_bounds__(256)
     rows[e] = v;
 }
 
-// The same matrix, built tile-wise: one block = 64 consecutive pixels of one image row.  The normalised
-// window p = msb/max of the tile (C x (2D+1) rows x (64+2D) columns, reflect-padded) is staged in LDS once --
+// The same matrix, built tile-wise: one block = 32 consecutive pixels of one image row (7.4 KB of LDS at the headline
+// shape: the launch fits beside the training workgroups of other fits, which leave 7.5 KB of a CU's LDS free, and
+// its 3.8 GB of stores ride under their MFMAs instead of holding the chip for 2.8 ms).  The normalised
+// window p = msb/max of the tile (C x (2D+1) rows x (32+2D) columns, reflect-padded) is staged in LDS once --
 // one IEEE division per staged value instead of two per output -- and the outputs leave in row-major order,
 // consecutive threads writing consecutive floats (the per-element kernel above spends its time in 64-bit
 // index divisions and scattered uint16 gathers: 0.7 TB/s; this one is bound by the 3.5 GB it writes).
-constexpr int BR_TW = 64;
+constexpr int BR_TW = 32;
 __global__ void __launch_bounds__(256)
     k_build_rows_tiled(lbdrn_geom g, int F, int RP, int LQs, const uint16_t* __restrict__ msb,
                        const uint16_t* __restrict__ img, float* __restrict__ rows)
@@ -1518,10 +1520,10 @@ static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
     }
 }
 
-template <int LQ, int NL>
+template <int LQ, int NL, int NT0C>
 static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
-    auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD>;
+    auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD, NT0C>;
     static std::atomic<unsigned long long> configured{0};
     if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
     kern<<<dim3((unsigned)nwg, (unsigned)count), STREAM_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
@@ -1532,11 +1534,18 @@ static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
     const bool one = A.net.nl == 1;
+    // the two shapes BASELINE.json names (F = 200: 13 strips, F = 250: 16) run the straight-line weight-gradient
+    // schedule; LBDRN_STREAM_LOOP=1 keeps them on the loop (A/B measurements)
+    static const bool loop_only = getenv("LBDRN_STREAM_LOOP") != nullptr;
     switch (A.p.LQ) {
-        case 16: return one ? launch_stream<16, 1>(A, nwg, count, s) : launch_stream<16, 2>(A, nwg, count, s);
-        case 32: return one ? launch_stream<32, 1>(A, nwg, count, s) : launch_stream<32, 2>(A, nwg, count, s);
-        case 52: return one ? launch_stream<52, 1>(A, nwg, count, s) : launch_stream<52, 2>(A, nwg, count, s);
-        default: return one ? launch_stream<64, 1>(A, nwg, count, s) : launch_stream<64, 2>(A, nwg, count, s);
+        case 16: return one ? launch_stream<16, 1, 0>(A, nwg, count, s) : launch_stream<16, 2, 0>(A, nwg, count, s);
+        case 32: return one ? launch_stream<32, 1, 0>(A, nwg, count, s) : launch_stream<32, 2, 0>(A, nwg, count, s);
+        case 52:
+            if (!one && A.p.NT0 == 13 && !loop_only) return launch_stream<52, 2, 13>(A, nwg, count, s);
+            return one ? launch_stream<52, 1, 0>(A, nwg, count, s) : launch_stream<52, 2, 0>(A, nwg, count, s);
+        default:
+            if (!one && A.p.NT0 == 16 && !loop_only) return launch_stream<64, 2, 16>(A, nwg, count, s);
+            return one ? launch_stream<64, 1, 0>(A, nwg, count, s) : launch_stream<64, 2, 0>(A, nwg, count, s);
     }
 }
 
