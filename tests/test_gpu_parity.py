@@ -201,7 +201,132 @@ def test_decode_big_rasters_hip_oracle_reference(golden, dev, tag):
         assert all(float(G["near_dist"][np.searchsorted(G["near_idx"], b)]) < 4e-5 for b in bad)
 
 
+@pytest.mark.parametrize("tag", ("bc64", "bc256", "embed", "scaled"))
+def test_decode_learnable_rasters_hip_oracle_reference(golden, dev, tag):
+    """The rasters of tests/golden/make_golden_round3.py -- fits that DO predict the low bits (residuals over 0..31,
+    PSNR 9-11 dB above "predict mid-range") and, for "scaled", sin arguments up to 361: HIP == oracle bit for bit on
+    every path; HIP differs from the reference raster only at listed near-boundary sub-pixels."""
+    G = golden["rasters_learn_" + tag]
+    img, K, D, bc, nl = G["img"], int(G["K"]), int(G["D"]), int(G["bc"]), int(G["nl"])
+    cfg = _cfg(G["flags"])
+    msb, _, mx = O.split_bits(img, K)
+    C, H, W = img.shape
+    out_o = O.decode(msb, K, D, _ocfg(cfg), G["params"], bc, nl, mx)
+    ref = ((img >> K) << K) + G["residual"]
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+    net = ops.make_net(cfg.feature_dim(C, D), bc, C, nl)
+    p_d, msb_d = torch.from_numpy(G["params"]).to(dev), ops.to_device_u16(msb, dev)
+    for path in (ops._lib.PATH_GENERIC, ops._lib.PATH_AUTO, ops._lib.PATH_MFMA):
+        out = ops.from_device_u16(ops.decode_fused(geom, net, msb_d, p_d, path=path))
+        assert np.array_equal(out, out_o), (tag, path)
+        bad = np.flatnonzero((out != ref).transpose(1, 2, 0).reshape(-1))
+        assert np.isin(bad, G["near_idx"]).all(), (tag, path)
+        assert bad.size <= (16 if tag == "scaled" else 2)
+
+
 # ---------------------------------------------------------------- a7, a8
+
+def _fused_steps_vs_fixture(dev, img, cfg, bc, params0, batches, lrs, losses_ref, bs):
+    """lbdrn_train_epoch(PATH_MFMA) fed a fixture's minibatches, `per` of them per call with one learning rate (the
+    fixture's "epochs"); returns (params, exp_avg, exp_avg_sq) after the last one, having checked every loss."""
+    C, H, W = img.shape
+    K, D = 5, 2
+    img_d = ops.to_device_u16(img, dev)
+    msb_d, mx = ops.split_bits(img_d, K)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+    net = ops.make_net(cfg.feature_dim(C, D), bc, C, 2)
+    p = torch.from_numpy(params0.copy()).to(dev)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    ws = ops.TrainWorkspace(geom, net, bs, dev).prepare(img_d, msb_d, ops._lib.PATH_MFMA)
+    s = 0
+    while s < len(batches):
+        e = s
+        while e < len(batches) and lrs[e] == lrs[s]:
+            e += 1
+        perm = torch.from_numpy(np.concatenate(batches[s:e])).to(dev)
+        losses = torch.zeros(e - s, dtype=torch.float32, device=dev)
+        ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, s, float(lrs[s]), losses, ops._lib.PATH_MFMA, ws)
+        for k in range(s, e):
+            assert abs(float(losses[k - s].item()) - float(losses_ref[k])) <= RTOL_TRAIN * float(losses_ref[k]), k
+        s = e
+    return p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy()
+
+
+def _f64_steps(x, t, params0, batches, F, bc, C, lrs):
+    """The same teacher-forced updates in float64 numpy (LBDRNmodel.py:79-82, LBDRNloss.py:9, torch/optim/adam.py):
+    what exact arithmetic gives, to tell a kernel's rounding from the reference run's own."""
+    x, t = x.astype(np.float64), t.astype(np.float64)
+    p = params0.astype(np.float64)
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    o1, o2, o3, o4, o5 = bc * F, bc * F + bc, bc * F + bc + bc * bc, bc * F + 2 * bc + bc * bc, bc * F + 2 * bc + bc * bc + C * bc
+    for s, b in enumerate(batches):
+        W0, b0, W1, b1 = p[:o1].reshape(bc, F), p[o1:o2], p[o2:o3].reshape(bc, bc), p[o3:o4]
+        W2, b2 = p[o4:o5].reshape(C, bc), p[o5:]
+        xb, tb = x[b], t[b]
+        z0 = xb @ W0.T + b0; h0 = np.sin(30 * z0)
+        z1 = h0 @ W1.T + b1; h1 = np.sin(30 * z1)
+        y = 1 / (1 + np.exp(-(h1 @ W2.T + b2)))
+        d = y - tb
+        dz2 = 2 * d / d.size * y * (1 - y)
+        dz1 = (dz2 @ W2) * np.cos(30 * z1) * 30
+        dz0 = (dz1 @ W1) * np.cos(30 * z0) * 30
+        g = np.concatenate([(dz0.T @ xb).ravel(), dz0.sum(0), (dz1.T @ h0).ravel(), dz1.sum(0), (dz2.T @ h1).ravel(), dz2.sum(0)])
+        m = 0.9 * m + 0.1 * g
+        v = 0.999 * v + 0.001 * g * g
+        st = s + 1
+        p = p - (lrs[s] / (1 - 0.9 ** st)) * m / (np.sqrt(v) / np.sqrt(1 - 0.999 ** st) + 1e-8)
+    return p, m, v
+
+
+def _as_close_to_float64_as_the_reference(name, hip, ref32, ref64):
+    """max |hip - float64| against max |reference float32 run - float64|, both relative to the largest entry: the
+    kernel may be as far from exact arithmetic as the reference's own run is (x2), or within 1e-5 outright."""
+    scale = np.abs(ref64).max()
+    err_ref, err_hip = np.abs(ref32 - ref64).max() / scale, np.abs(hip - ref64).max() / scale
+    assert err_hip <= max(1e-5, 2 * err_ref), (name, err_hip, err_ref)
+    return err_ref
+
+
+def test_wide_train_kernel_matches_reference_fixture(golden, dev):
+    """BASELINE.json configs[2]'s training kernel (k_train_wide, bc = 256) eats the reference's train256 fixture: image
+    A_K5_D2's rows, the fixture's three 128-row minibatches through lbdrn_train_epoch(PATH_MFMA).  Loss within 1e-5
+    at every step and final parameters within 2e-5 of the reference run.  The Adam moments are held to what float32
+    can give at this width: the reference's own float32 run sits 5.3e-5 (exp_avg) / 6.8e-5 (exp_avg_sq) of the largest
+    moment away from the same three steps evaluated in float64 (dots of 256 terms, sin(30 z) in between), so the
+    kernel is measured against the float64 values and must be as close to them as the reference run is (x2)."""
+    G, T2, Ft = golden["wide_net"], golden["train2"], golden["features"]
+    batches = list(G["train256/batches"])
+    p, m, v = _fused_steps_vs_fixture(dev, Ft["A_K5_D2/img"], FeatCfg(), 256, G["train256/params0"], batches,
+                                      [1e-3] * 3, [G[f"train256/step{s}/loss"] for s in range(3)], 128)
+    pr = G["train256/params_final"]
+    assert np.linalg.norm(p - pr) <= 2e-5 * np.linalg.norm(pr)
+    p64, m64, v64 = _f64_steps(Ft["A_K5_D2/features"], Ft["A_K5_D2/labels"], G["train256/params0"], batches, 200, 256, 8, [1e-3] * 3)
+    for name, hip, ref32, ref64 in (("exp_avg", m, T2["wide256/exp_avg"], m64), ("exp_avg_sq", v, T2["wide256/exp_avg_sq"], v64)):
+        err_ref = _as_close_to_float64_as_the_reference(name, hip, ref32, ref64)
+        assert 2e-5 < err_ref < 1e-4, (name, err_ref)          # the fixture's own float32 rounding, as measured
+    assert np.linalg.norm(p - p64) <= 2 * np.linalg.norm(pr - p64) + 1e-6 * np.linalg.norm(p64)
+
+
+def test_embedding_train_kernel_matches_reference_fixture(golden, dev):
+    """BASELINE.json configs[4]'s training kernel (the streamed step at LQ = 64, F = 250: coordinates + Fourier
+    embedding ahead of the colours) eats a reference fixture of its own: six teacher-forced 96-row updates on an
+    8 x 24 x 20 image, StepLR chain included -- loss 1e-5 per step, parameters 1e-5, and Adam moments as close to
+    the float64 evaluation of the same six steps as the reference's float32 run is (x2; measured: the reference
+    2e-5 of the largest moment, a few entries of 20,744)."""
+    T = golden["train2"]
+    cfg = _cfg(T["embed/flags"])
+    lrs = [float(T[f"embed/step{s}/lr"]) for s in range(6)]
+    batches = list(T["embed/batches"])
+    p, m, v = _fused_steps_vs_fixture(dev, T["embed/img"], cfg, 64, T["embed/params0"], batches, lrs,
+                                      [T[f"embed/step{s}/loss"] for s in range(6)], 96)
+    pr = T["embed/step5/params"]
+    assert np.linalg.norm(p - pr) <= 1e-5 * np.linalg.norm(pr)
+    msb, lab, mx = O.split_bits(T["embed/img"], 5)
+    feats = O.features(msb, 2, _ocfg(cfg), mx)          # (bit-identical to the reference's process(): test_oracle_golden)
+    p64, m64, v64 = _f64_steps(feats, lab, T["embed/params0"], batches, 250, 64, 8, lrs)
+    _as_close_to_float64_as_the_reference("exp_avg", m, T["embed/exp_avg"], m64)
+    _as_close_to_float64_as_the_reference("exp_avg_sq", v, T["embed/exp_avg_sq"], v64)
+
 
 def test_fused_train_kernel_matches_reference_fixture(golden, dev):
     """The fused training kernels themselves (lbdrn_train_epoch, PATH_MFMA) eat the reference fixture: image

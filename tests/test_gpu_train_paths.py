@@ -78,7 +78,10 @@ def test_mfma_epoch_matches_generic_and_oracle(dev, case):
     for path in (GEN, MFMA):
         p, m, v, losses = res[path]
         np.testing.assert_allclose(losses, np.array(lo), rtol=1e-5), path   # north_star tolerance
-        wide = 4.0 if bc > 64 else 1.0   # dots of 256 terms and 4x the partial sums: measured 4e-5 on the moments at bc = 256
+        # bc > 64: two float32 evaluations of these steps differ by that much -- torch's own run of the bc = 256 fixture sits
+        # 5.3e-5 / 6.8e-5 of the largest moment away from float64 (test_wide_train_kernel_matches_reference_fixture measures
+        # both sides against float64); the oracle here is float32 too
+        wide = 4.0 if bc > 64 else 1.0
         assert np.linalg.norm(p - po) <= 2e-5 * np.linalg.norm(po), path
         assert np.abs(m - mo).max() <= wide * 2e-5 * np.abs(mo).max(), path
         assert np.abs(v - vo).max() <= wide * 5e-5 * np.abs(vo).max(), path
@@ -406,6 +409,30 @@ def test_background_evaluation_pass_is_the_same_sum(dev, shape):
         fits.append(codec.fit_device(img_d, 5, 2, 64, 2, 1e-3, 256, 3, alone=alone))
     assert torch.equal(fits[0].best_params.view(torch.int32), fits[1].best_params.view(torch.int32))
     assert torch.equal(fits[0].mse_log, fits[1].mse_log)
+
+
+def test_fit_learns_what_the_torch_port_learns(golden, dev):
+    """A fit that has something to learn: the smooth 8 x 128 x 128 image of the learnable reference rasters
+    (tests/golden/make_golden_round3.py; its low bits follow from the neighbours' high bits), 90 epochs = 180 Adam steps,
+    same seed and draws on both sides.  The HIP fit and the torch-CPU restatement of the reference loop
+    (oracle/torch_port.py) must reach the same reconstruction quality -- PSNR within 0.05 dB of each other -- and that
+    quality must be well above "predict mid-range" (the assertion a noise tile cannot make)."""
+    import torch_port as TP
+    img = golden["rasters_learn_bc64"]["img"]
+    K, D, bc, nl, lr, bs, epochs = 5, 2, 64, 2, 1e-3, 8192, 90
+    torch.manual_seed(19920517)
+    r = TP.fit(img, K, D, bc, nl, lr, bs, epochs, faithful=False)
+    rec_t = TP.apply(r["msb"], container.truncate_precision(r["params"], 16), K, D, bc, nl)
+    torch.manual_seed(19920517)
+    fit = codec.fit_device(ops.to_device_u16(img, dev), K, D, bc, nl, lr, bs, epochs)
+    rec_h = ops.from_device_u16(codec.apply_device(fit.geom, fit.net, fit.msb, codec.truncate_device(fit.best_params, 16)))
+    psnr = lambda rec: 10 * np.log10(10000.0 ** 2 / np.mean((rec.astype(np.float64) - img.astype(np.float64)) ** 2))
+    mid = psnr(((img >> K) << K) + 16)
+    p_t, p_h = psnr(rec_t), psnr(rec_h)
+    assert p_t > mid + 4.0 and p_h > mid + 4.0, (mid, p_t, p_h)
+    assert abs(p_t - p_h) <= 0.05, (p_t, p_h)
+    best_t = min(m for _, m, _ in r["epoch_mse"])
+    assert abs(float(fit.mse_log[:, 0].min().item()) - best_t) <= 5e-3 * best_t
 
 
 def test_fits_in_flight_together_equal_fits_one_by_one(dev):
