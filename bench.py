@@ -55,6 +55,7 @@ def parse():
                    help="BASELINE.json configs[4]: USE_COORDINATES=True + EMBEDDING=True (F = 250)")
     p.add_argument("--in-flight", type=int, default=4,
                    help="tiles progressing at a time on each GPU (independent fits on their own streams)")
+    p.add_argument("--repeats", type=int, default=3, help="repeats of the timed region; the median is reported")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline crop")
     p.add_argument("--cpu-epochs", type=int, default=1,
@@ -96,13 +97,25 @@ def event_time_ms(fn, stream, repeat=1):
     return s.elapsed_time(e) / repeat
 
 
+def config_key(a):
+    """Which profiled configuration of profiles/pmc_summary.json this run is (None: not one of them)."""
+    if a.bands == 8 and a.K == 5 and a.D == 2 and a.nl == 2:
+        if a.coords_embedding and a.bc == 64:
+            return "embed"
+        if not a.coords_embedding and a.bc in (64, 256):
+            return f"bc{a.bc}"
+    return None
+
+
 def roofline_probe(codec, ops, fit, img_d, a, path):
     """Live HIP-event timing, on the launch stream, right after the timed region (same process, same tile).
-    Dominant kernel = the fused training step k_train_wave (5120 launches per tile, 60 % of the GPU time of a fit):
-    one real 512-step epoch (train, reduce/Adam, train, ...) between one event pair, and one with every reduce
-    launch doubled (lbdrn_train_profile_mode) -- the difference isolates the reduce kernel, the rest of a step is the
-    train kernel (plus its launch gap).  The fused apply kernel is reported beside it.  Counter-derived fields
-    (traffic, mfma_busy_frac) come from the committed rocprofv3 --pmc summary of the same kernels."""
+    Dominant kernel = the fused training step (5120 launches per tile, ~55 % of the GPU time of a fit).  ONE source for
+    both kernels of a step: a real 512-step epoch (train, reduce/Adam, train, ...) between one event pair, then the same
+    epoch with every training launch doubled and with every reduce launch doubled (lbdrn_train_profile_mode): the
+    differences are what one more launch of either kernel costs inside the dependent sequence, launch boundary included;
+    what the pair costs beyond the two is reported as `unaccounted_us`.  The fused apply kernel is reported beside it.
+    Counter-derived fields (traffic, mfma_busy_frac) come from the committed rocprofv3 --pmc summary of the same
+    kernels at this configuration (profiles/pmc_summary.json, keyed by configuration and kernel)."""
     stream = torch.cuda.current_stream()
     geom, net = fit.geom, fit.net
     N = geom.H * geom.W
@@ -116,27 +129,33 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path)
     run_epoch = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0, 1e-6, None, path, tws)
     run_epoch()
-    t_epoch = event_time_ms(run_epoch, stream, 1)
     nsteps = (N + a.bs - 1) // a.bs
     peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
     B = min(a.bs, N)
     out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "traffic": None}
+    t = {}
     try:
-        ops.train_profile_mode(1)
-        t_epoch2 = event_time_ms(run_epoch, stream, 1)
+        for mode in (0, 2, 1, 0):     # plain, training launch doubled, reduce launch doubled, plain again
+            ops.train_profile_mode(mode)
+            t.setdefault(mode, []).append(event_time_ms(run_epoch, stream, 1))
     finally:
         ops.train_profile_mode(0)
-    t_reduce = (t_epoch2 - t_epoch) / nsteps
-    fused = t_reduce > 0.5e-3   # a fused MFMA train kernel is in use (the generic path ignores the mode)
+    t_epoch = min(t[0])
+    t_train, t_reduce = (t[2][0] - t_epoch) / nsteps, (t[1][0] - t_epoch) / nsteps
+    fused = t_reduce > 0.5e-3   # a fused MFMA train kernel is in use (the generic path ignores the modes)
+    name = "k_train_wide" if net.bc > 64 else "k_train_stream"
     if fused:
-        t_k = t_epoch / nsteps - t_reduce
-        out.update({"kernel": "k_train_wave (row gather + forward + loss + backward + weight-gradient slab of one 8192-row "
+        t_k = t_train
+        out.update({"kernel": f"{name} (row gather + forward + loss + backward + weight-gradient slab of one {B}-row "
                               "minibatch: 128 workgroups of 64 rows, one per CU, on half of the chip's 256 CUs)",
-                    "kernel_us": round(t_k * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
+                    "kernel_us": round(t_train * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
+                    "unaccounted_us": round((t_epoch / nsteps - t_train - t_reduce) * 1e3, 2),
                     "flop_per_launch": step * B, "cus_occupied": min(256, (B + 63) // 64),
-                    "timing": "HIP events over one 512-step epoch of ONE fit on the launch stream, and over one with the reduce "
-                              "launch doubled; kernel_us = step - reduce (it contains the launch gap).  rocprofv3 --kernel-trace of "
-                              "the one-fit sequence: profiles/*_kernel_stats_one_in_flight.csv"})
+                    "timing": "HIP events on the launch stream over one 512-step epoch of ONE fit, and over the same epoch with "
+                              "every training launch doubled / every reduce launch doubled: kernel_us and reduce_adam_us are what one "
+                              "more launch of that kernel costs in the dependent sequence (its launch boundary included), "
+                              "train_step_pair_us the whole step, unaccounted_us the rest.  rocprofv3 --kernel-trace averages of the "
+                              "same sequence: profiles/r03_kernel_stats_one_in_flight.csv"})
     else:  # shape without a fused train kernel: the generic step is many launches
         t_k = t_epoch / nsteps
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
@@ -152,14 +171,19 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
         # the CUs it occupies
         out["frac_of_occupied_cus"] = round(ach / (peak * out["cus_occupied"] / 256.0), 4)
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")   # committed rocprofv3 --pmc summary, if any
-    if os.path.exists(pmc) and fused:
+    key = config_key(a)
+    if os.path.exists(pmc) and fused and key and N == 2048 * 2048:
         try:
             d = json.load(open(pmc))
-            out["traffic"] = d.get("k_train_wave_hbm_bytes_per_launch")
-            out["traffic_algorithmic_bytes"] = d.get("algorithmic_bytes_per_train_launch")
-            out["mfma_busy_frac"] = d.get("k_train_wave_mfma_busy_frac_whole_chip")
-            out["mfma_busy_frac_occupied_simds"] = d.get("k_train_wave_mfma_busy_frac_occupied_simds")
-            out["apply_mfma_busy_frac"] = d.get("k_apply_mfma_eval_mfma_busy_frac_whole_chip")
+            c = d.get("configs", {}).get(key, {})
+            tr, ap = c.get("train", {}), c.get("apply_eval", {})
+            out["traffic"] = tr.get("hbm_bytes_per_launch")
+            out["traffic_algorithmic_bytes"] = B * 16
+            out["traffic_kernel"] = tr.get("kernel")
+            out["mfma_busy_frac"] = tr.get("mfma_busy_frac_whole_chip")
+            out["mfma_busy_frac_occupied_simds"] = tr.get("mfma_busy_frac_occupied_simds")
+            out["lds_bank_conflict_cycles_per_launch"] = tr.get("lds_bank_conflict_cycles_per_launch")
+            out["apply_mfma_busy_frac"] = ap.get("mfma_busy_frac_whole_chip")
             out["counters_source"] = d.get("source")
         except Exception:
             pass
@@ -173,7 +197,9 @@ def cpu_baseline(a):
     full `-e` epochs.  Form A (the headline): map-style dataset + DataLoader(shuffle, bs,
     num_workers=min(32, cores)) + per-step Adam + concatenating whole-image metric, i.e. the reference's cost
     structure; form B beside it: index_select minibatches + streaming MSE (math only).  GDAL / fpzip / file I/O
-    excluded from both."""
+    excluded from both.  The CPU's best is what is reported: form B is timed at torch.set_num_threads in
+    {8, 16, 32, 64, all} (a 64 x 200 GEMM on 8192 rows does not use 128 threads well), form A then runs at the thread
+    count that served form B best; every measurement and its thread count are in the line."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
     import torch_port as TP
@@ -183,8 +209,10 @@ def cpu_baseline(a):
     ocfg = O.FeatCfg(use_coordinates=a.coords_embedding, embedding=a.coords_embedding)
     ep = max(2, min(a.cpu_epochs, a.epochs)) if a.epochs > 1 else 1
     workers = min(32, os.cpu_count() or 1)
-    out = {}
-    for form, faithful in (("A", True), ("B", False)):
+    all_threads = torch.get_num_threads()
+
+    def run(faithful, threads):
+        torch.set_num_threads(threads)
         torch.manual_seed(SEED)
         t0 = time.time()
         r = TP.fit(img, a.K, a.D, a.bc, a.nl, a.lr, a.bs, ep, cfg=ocfg, faithful=faithful,
@@ -195,16 +223,28 @@ def cpu_baseline(a):
         t0 = time.time()
         TP.apply(r["msb"], r["params"], a.K, a.D, a.bc, a.nl, cfg=ocfg)
         t_dec = time.time() - t0
-        out[form] = (side * side / (t_enc + t_dec) / 1e6, t_enc, t_dec, t_call)
-    return {"value": round(out["A"][0], 6), "unit": "Mpixels/s", "cores": torch.get_num_threads(),
+        return side * side / (t_enc + t_dec) / 1e6, t_enc, t_dec, t_call
+
+    try:
+        sweep = {}
+        for th in sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads}):
+            sweep[th] = run(False, th)
+        best_th = max(sweep, key=lambda th: sweep[th][0])
+        form_a = run(True, best_th)
+    finally:
+        torch.set_num_threads(all_threads)
+    fb = sweep[best_th]
+    return {"value": round(form_a[0], 6), "unit": "Mpixels/s", "cores": best_th,
             "host_cpus": os.cpu_count(), "kind": "port", "loader_workers": workers,
-            "vectorised_form_B": round(out["B"][0], 6),
+            "vectorised_form_B": round(fb[0], 6),
+            "form_B_by_threads": {str(th): round(v[0], 6) for th, v in sweep.items()},
             "sample": f"{side}x{side}x{a.bands} crop of tile 0 ({(side * side + a.bs - 1) // a.bs} minibatches per pass), "
                       f"{ep} of {a.epochs} epochs measured (bs={a.bs}; every epoch = one training pass + one evaluation "
-                      f"pass) and scaled to {a.epochs}; form A = DataLoader(num_workers={workers}) + per-step Adam + "
-                      f"concatenating eval metric: measured {out['A'][3]:.1f}s -> encode {out['A'][1]:.1f}s decode "
-                      f"{out['A'][2]:.1f}s; form B = index_select batches + streaming MSE: measured {out['B'][3]:.1f}s "
-                      f"-> encode {out['B'][1]:.1f}s decode {out['B'][2]:.1f}s"}
+                      f"pass) and scaled to {a.epochs}; torch threads swept over {sorted(sweep)} on form B (index_select "
+                      f"batches + streaming MSE), best at {best_th}: measured {fb[3]:.1f}s -> encode {fb[1]:.1f}s decode "
+                      f"{fb[2]:.1f}s; form A (the value) = DataLoader(num_workers={workers}) + per-step Adam + "
+                      f"concatenating eval metric at {best_th} threads: measured {form_a[3]:.1f}s -> encode {form_a[1]:.1f}s "
+                      f"decode {form_a[2]:.1f}s"}
 
 
 def launch_ranks(a):
@@ -223,13 +263,18 @@ def launch_ranks(a):
         port = sk.getsockname()[1]
     import tempfile
     procs = []
-    with tempfile.TemporaryFile("w+") as line0:
+    with tempfile.TemporaryDirectory(prefix="lbdrn_bench_") as logdir:
+        logs = []
         for r in range(a.gpus):
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                        MASTER_PORT=str(port),
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            # every rank's stdout and stderr are kept: when a rank fails, what IT said is what gets printed
+            out_f = open(os.path.join(logdir, f"rank{r}.out"), "w+")
+            err_f = open(os.path.join(logdir, f"rank{r}.err"), "w+")
+            logs.append((out_f, err_f))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=line0 if r == 0 else subprocess.DEVNULL))
+                                          stdout=out_f, stderr=err_f))
         # a rank that dies leaves the others waiting in a rendezvous or a barrier: stop them (by PID) right away
         while any(p.poll() is None for p in procs):
             if any(p.poll() not in (None, 0) for p in procs):
@@ -239,31 +284,48 @@ def launch_ranks(a):
                 break
             time.sleep(0.1)
         codes = [p.wait() for p in procs]
-        line0.seek(0)
-        for ln in line0.read().splitlines():      # the JSON line only (gloo announces its connections on stdout)
+
+        def text(f):
+            f.flush()
+            f.seek(0)
+            return f.read()
+        for ln in text(logs[0][0]).splitlines():      # the JSON line only (gloo announces its connections on stdout)
             if ln.startswith("{"):
                 print(ln)
             elif ln.strip():
                 print(ln, file=sys.stderr)
         sys.stdout.flush()
-    if any(codes):
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        return 1
-    return 0
+        if any(codes):
+            print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+            first_bad = [r for r, c in enumerate(codes) if c not in (0, -15)] or [r for r, c in enumerate(codes) if c]
+            for r in first_bad[:2]:
+                tail = "\n".join((text(logs[r][1]) + text(logs[r][0]) if r else text(logs[r][1])).splitlines()[-25:])
+                print(f"---- rank {r} (exit code {codes[r]}), last lines:\n{tail}", file=sys.stderr)
+        else:
+            sys.stderr.write(text(logs[0][1]))
+        for o, e in logs:
+            o.close()
+            e.close()
+    return 1 if any(codes) else 0
 
 
 def dry_run(a, rank, world):
     """LBDRN_BENCH_DRYRUN=1: the launcher and the exchange only (gloo, no GPU call) -- what the CPU test of
     `--gpus 2` runs; prints the shape of the bench line with no measurement in it."""
     from lbdrn_hip import shard
+    if os.environ.get("LBDRN_BENCH_DRYRUN_FAIL") == str(rank):   # rehearsal of a failing rank (tests)
+        print(f"rank {rank}: simulated failure before the rendezvous", file=sys.stderr)
+        return 7
     if world > 1:
         dist.init_process_group("gloo")
     mine = shard.assign((a.warmup + a.steps) * world, rank, world)
     records = shard.gather_records([[float(i), 0.0, 0.0] for i in mine[a.warmup:]], 3)
     elapsed = shard.max_over_ranks(1.0 + rank)
+    per_rank = shard.gather_records([[float(rank), 1000.0 * (1.0 + rank)]], 2)
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "records": records,
-                          "max_over_ranks": elapsed}))
+                          "max_over_ranks": elapsed, "rank_elapsed_ms": [r[1] for r in sorted(per_rank)],
+                          "ranks_seen": dist.get_world_size() if world > 1 else 1}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -322,11 +384,20 @@ def main():
     # (measured on configs[4]: 154 instead of 96 ms per tile with a single round)
     for _ in range(2 if a.warmup else 0):
         run_images(codec, ops, tiles[:a.warmup] * max(1, min(a.in_flight, a.steps)), a, path)
-    barrier()
-    t0 = time.perf_counter()
-    done = run_images(codec, ops, tiles[a.warmup:], a, path)
-    barrier()
-    elapsed = shard.max_over_ranks(time.perf_counter() - t0, xdev)
+    # the timed region -- exactly K tiles per GPU between two barrier + synchronize pairs, maximum over the ranks -- runs
+    # `--repeats` times (default 3); the line carries the MEDIAN repeat and the spread
+    rep_laps, own = [], []
+    for _ in range(a.repeats):
+        barrier()
+        t0 = time.perf_counter()
+        done = run_images(codec, ops, tiles[a.warmup:], a, path)
+        barrier()
+        own.append(time.perf_counter() - t0)
+        rep_laps.append(shard.max_over_ranks(own[-1], xdev))
+    order = sorted(range(a.repeats), key=lambda k: rep_laps[k])
+    mid = order[len(order) // 2]
+    elapsed = rep_laps[mid]
+    rank_elapsed = shard.gather_records([[float(rank), own[mid] * 1e3]], 2, xdev)   # every rank's own clock, that repeat
 
     # per-image metric records (after the clock): [image index, reconstruction MSE, best evaluation MSE] for every
     # timed tile -- the only data the ranks exchange
@@ -366,6 +437,9 @@ def main():
             "metric": "Mpixels/s encode+decode (and bpp/PSNR parity) on D2/K5/bc64/nl2",
             "value": round(value, 4), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(elapsed / a.steps * 1e3, 3),
+            "repeats": a.repeats, "ms_per_step_all_repeats": [round(t / a.steps * 1e3, 3) for t in rep_laps],
+            "rank_elapsed_ms": [round(r[1], 3) for r in sorted(rank_elapsed)],
+            "ranks_seen": dist.get_world_size() if world > 1 else 1,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {a.bands}-band {a.height}x{a.width} uint16 tile per step, "

@@ -150,11 +150,13 @@ int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom *const *g, const lbd
                             void *const *workspace, size_t workspace_bytes, int32_t path, void *stream);
 
 /* DIAGNOSTIC, not part of the codec path: a measurement aid of bench.py's roofline leg, and the one piece of mutable
- * state this library keeps besides the error string -- thread-local, off (0) unless a caller sets it.  mode 1: every step of lbdrn_train_epoch on this thread
- * launches its reduce/Adam kernel twice (the second with a zero step size), mode 0: normal.  Timing one
- * epoch in each mode with a single HIP-event pair gives t_reduce = t(mode 1) - t(mode 0) per step and
- * t_train_kernel = t(mode 0) - t_reduce, both inside the real launch sequence and without per-launch event
- * packets (which cost more than the ~0.4 us gaps they would measure).  Use on scratch optimiser state. */
+ * state this library keeps besides the error string -- thread-local, off (0) unless a caller sets it.  mode 1: every step
+ * of lbdrn_train_epoch on this thread launches its reduce/Adam kernel twice (the second with a zero step size); mode 2:
+ * its training kernel twice (the launch is idempotent: it writes its gradient slabs and loss partials); mode 0: normal.
+ * Timing one epoch in each mode with a single HIP-event pair gives, per step, t_reduce = t(mode 1) - t(mode 0) and
+ * t_train = t(mode 2) - t(mode 0) -- what one more launch of that kernel costs inside the real dependent sequence,
+ * its launch boundary included -- without per-launch event packets (which cost more than the gaps they would
+ * measure).  Use on scratch optimiser state. */
 int lbdrn_train_profile_mode(int32_t mode);
 
 /* a4 -- the minibatch order: perm[0..n) = torch.randperm(n, generator=torch.Generator().manual_seed(seed))

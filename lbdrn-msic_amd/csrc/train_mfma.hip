@@ -1443,6 +1443,29 @@ __global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
 #endif
 }
 
+// the dynamic-LDS ceiling of a kernel is told to the runtime once per device and kernel (a cache of an idempotent
+// setting; several host threads may get here together)
+template <class K>
+static int configure_lds_once(K kern, int bytes, std::atomic<unsigned long long>& configured)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(configured.load(std::memory_order_relaxed) & bit)) {
+        LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        configured.fetch_or(bit, std::memory_order_relaxed);
+    }
+    return 0;
+}
+
+// measurement aid (see lbdrn_hip.h): mode 1 doubles the reduce/Adam launch of every step, mode 2 the training launch
+static thread_local int g_prof_mode = 0;
+int train_profile_mode(int mode)
+{
+    g_prof_mode = mode;
+    return 0;
+}
+
 #include "train_stream.inc"
 
 static int stream_lds_total(int LQ, int NL) { return stream_lds(LQ, NL).total; }
@@ -1462,21 +1485,6 @@ static size_t wide_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 }
 
 // ------------------------------------------------------------------ host driver
-
-// the dynamic-LDS ceiling of a kernel is told to the runtime once per device and kernel (a cache of an idempotent
-// setting; several host threads may get here together)
-template <class K>
-static int configure_lds_once(K kern, int bytes, std::atomic<unsigned long long>& configured)
-{
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (!(configured.load(std::memory_order_relaxed) & bit)) {
-        LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        configured.fetch_or(bit, std::memory_order_relaxed);
-    }
-    return 0;
-}
 
 template <int LQ, int NL>
 static int launch_train(const TrainArgs& A, int nwg, hipStream_t s)
@@ -1602,13 +1610,6 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     return 0;
 }
 
-// measurement aid (see lbdrn_hip.h): mode 1 doubles the reduce/Adam launch of every step
-static thread_local int g_prof_mode = 0;
-int train_profile_mode(int mode)
-{
-    g_prof_mode = mode;
-    return 0;
-}
 
 // One epoch of `count` fits of one shape, stepping side by side (count == 1: the plain call).  Groups of more than
 // one fit run on the streamed step only: minibatch s of every fit is ONE launch of count x nwg workgroups
@@ -1684,6 +1685,8 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
         A.perm_next = perm[0] + first + bs;
         A.next_n = (int)nextB;
         if (int rc = dispatch_train(A, nwg, count, s)) return rc;
+        if (g_prof_mode == 2)   // measurement only: the same launch again (it writes the same slabs and loss partials)
+            if (int rc = dispatch_train(A, nwg, count, s)) return rc;
         ++step;
         const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
         k_reduce_adam<<<red_grid, 256, 0, s>>>(R, nwg, A.p.slab_floats, map, (float)(lr / bc1), (float)std::sqrt(bc2),

@@ -26,7 +26,7 @@ from LBDRNdataset import tile_windows
 DEVICE = "cuda:0"
 BASE_CODEC = os.environ.get("LBDRN_BASE_CODEC", "LBB2")   # "LBB1": the portable host payload of older files
 IN_FLIGHT = int(os.environ["LBDRN_IN_FLIGHT"]) if "LBDRN_IN_FLIGHT" in os.environ else None   # tiles of one image
-# progressing at a time on a GPU (None: codec.fit_many decides -- 2, or 4 for small tiles)
+# progressing at a time on a GPU (None: codec.fit_many's default, 4)
 
 
 def write_image_header(header_path, split_ratio, width, height, K, bc, nl, D, nn_bytes_list,

@@ -91,7 +91,6 @@ class DeviceFit:
 _RNG_LOCK = threading.Lock()   # the global torch CPU generator is one per process
 _POOL_LOCK = threading.Lock()
 _FIT_STREAMS = {}               # device -> streams the fits in flight run on
-_OVERLAP_OK = {}                # device -> True / False once a fit has measured whether background passes pay there
 
 
 def _fit_stream_pool(dev, n):
@@ -101,6 +100,24 @@ def _fit_stream_pool(dev, n):
         while len(pool_) < n:
             pool_.append(torch.cuda.Stream(device=dev))
         return pool_
+
+
+def overlap_evaluation(dev, alone):
+    """Whether a fit's evaluation passes run in the background of its next epoch (fit_device).  A stated policy, not a
+    measurement: LBDRN_OVERLAP_EVAL=0 / 1 decides outright (run.sh and sweep.py export 0 when they put several
+    processes on one GPU: `alone` only knows about this process); otherwise the passes go to the background when the
+    fit is alone in its process AND every stream the process then uses on this device -- the caller's, the fit
+    streams made so far (at least two), the permutation side stream -- still gets a hardware queue of its own
+    (GPU_MAX_HW_QUEUES, the runtime's default is 4): a background pass that shares a queue with the training chain
+    costs 3x the fit instead of saving 5 % of it (scripts/ab_streamidx.py).  Results are bit-identical either way."""
+    env = os.environ.get("LBDRN_OVERLAP_EVAL")
+    if env in ("0", "1"):
+        return env == "1"
+    if not alone:
+        return False
+    with _POOL_LOCK:
+        fit_streams = max(2, len(_FIT_STREAMS.get(dev, [])))
+    return fit_streams + 2 <= int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
 
 
 def _eval_stream(dev, main):
@@ -123,9 +140,9 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     iterator per train / eval pass (lbdrn_hip.sampler).  With `seed`, the fit seeds the generator
     itself and makes all its draws in one critical section, so that fits running on several
     threads (fit_many) each see what a freshly seeded process would; with `draws` (draw_fit) the generator
-    is not touched at all.  `alone`: this fit has the device to itself (no other fit in flight) -- its
-    evaluation passes then run in the background of the next epoch's training (below).  No host synchronisation
-    happens inside except the scalar read of MSB.max() that sizes the normalisation
+    is not touched at all.  `alone`: no other fit is in flight in this process -- its evaluation passes then run
+    in the background of the next epoch's training where overlap_evaluation() allows it (below).  No host
+    synchronisation happens inside except the scalar read of MSB.max() that sizes the normalisation
     (ref LBDRNdataset.py:120)."""
     cfg = cfg or FeatCfg.from_constants()
     out = DeviceFit()
@@ -166,46 +183,31 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     # the chain.  With other fits in flight the chip is full anyway and a whole-chip pass in the chain is faster
     # (measured).  Which epoch was best is settled after the last pass: same rule, same order.
     main = torch.cuda.current_stream(dev)
-    if os.environ.get("LBDRN_OVERLAP_EVAL") in ("0", "1"):   # A/B measurements
-        alone = os.environ["LBDRN_OVERLAP_EVAL"] == "1"
-    side = _eval_stream(dev, main) if alone and len(eval_epochs) > 1 and _OVERLAP_OK.get(dev, True) else None
-    # ... and since other users of the process may hold every hardware queue already, the fit checks once per device
-    # (without waiting for anything) that its second epoch, which has a pass beside it, was not much slower than its
-    # first; if it was, the passes go back into the chain
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if side is not None and dev not in _OVERLAP_OK else None
+    side = _eval_stream(dev, main) if len(eval_epochs) > 1 and overlap_evaluation(dev, alone) else None
     snaps = torch.empty((max(len(eval_epochs), 1), params.numel()), dtype=torch.float32, device=dev)
     mses = torch.zeros((max(len(eval_epochs), 1),), dtype=torch.float32, device=dev)
     if side is not None:
         side.wait_stream(main)       # the workspaces and the planes above are ready
     adam_steps = 0
-    for e in range(1, epochs + 1):
-        perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
-        if marks is not None:
-            if e <= 3:
-                marks[e - 1].record(main)
-            elif dev not in _OVERLAP_OK and marks[2].query():
-                _OVERLAP_OK[dev] = marks[1].elapsed_time(marks[2]) < 1.6 * marks[0].elapsed_time(marks[1])
-                if not _OVERLAP_OK[dev]:
-                    main.wait_stream(side)
-                    side = None
-        ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
-                        adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
-        adam_steps += steps_per_epoch
-        if e in eval_epochs:                                              # encode.py:104-117
-            k = eval_epochs.index(e)
-            snaps[k].copy_(params)
-            if side is not None:
-                side.wait_stream(main)
-            with torch.cuda.stream(side if side is not None else main):
-                background = side is not None and e != epochs      # nothing trains beside the last pass
-                sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background)   # a9
-                mses[k:k + 1].copy_((sse / float(N * C)).float())
-            out.evaluated.append(e)
-    if side is not None:
-        main.wait_stream(side)
-    if marks is not None and dev not in _OVERLAP_OK and epochs >= 3:   # a short fit: settle it now (the fit is over anyway)
-        marks[2].synchronize()
-        _OVERLAP_OK[dev] = marks[1].elapsed_time(marks[2]) < 1.6 * marks[0].elapsed_time(marks[1])
+    try:
+        for e in range(1, epochs + 1):
+            perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
+            ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
+                            adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
+            adam_steps += steps_per_epoch
+            if e in eval_epochs:                                              # encode.py:104-117
+                k = eval_epochs.index(e)
+                snaps[k].copy_(params)
+                if side is not None:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side if side is not None else main):
+                    background = side is not None and e != epochs      # nothing trains beside the last pass
+                    sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background)   # a9
+                    mses[k:k + 1].copy_((sse / float(N * C)).float())
+                out.evaluated.append(e)
+    finally:
+        if side is not None:       # whatever happened, the borrowed stream is joined before anybody else uses it
+            main.wait_stream(side)
     best_params = params.clone() if epochs == 1 else draws_params0      # encode.py:100-103 / :91
     best_mse = torch.full((1,), 1e6, dtype=torch.float32, device=dev)   # encode.py:91
     for k, e in enumerate(eval_epochs):

@@ -1,43 +1,47 @@
 #!/bin/bash
-# Profile pass of a round, run ON the GPU box (gpurun): scripts/profile_round.sh TAG [kt|pmc|sq ...]
+# Profile pass of a round, run ON the GPU box (gpurun): scripts/profile_round.sh TAG [kt|cfg|pmc|sq ...]
 #   kt   rocprofv3 --kernel-trace --stats of bench.py with one fit in flight and with the default (four)
-#   pmc  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (--kernel-trace only) -> per-kernel mean bytes
-#   sq   two SQ counter passes (8 counters each) -> per-kernel means
+#   cfg  the same for BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING)
+#   pmc  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (--kernel-trace only), per configuration
+#        (bc64, bc256, embed) -> per-kernel mean bytes
+#   sq   two SQ counter passes (8 counters each) per configuration -> per-kernel means
 # Small CSVs land under gpurun_out/prof_TAG/; the databases are deleted as soon as they are summarised.
-TAG=${1:-r02}; shift
-WHAT=${@:-kt pmc sq cfg}
+# (the program itself follows `--`: the profiler's library has initialised the GPU by then)
+TAG=${1:-r03}; shift
+WHAT=${@:-kt cfg pmc sq}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-CMD1="python3 bench.py --no-cpu-baseline --in-flight 1 --steps 1 --warmup 0"
-CMDP="python3 scripts/prof_fit.py 2048 64 4"   # counter passes: one fit at a time, 4 epochs x 2 fits (rocprofv3 --pmc dies past ~16 k dispatches)
 summarise() { # dir out-csv script [filters]
   DB=$(find $1 -name "*.db" | head -1)
   if [ -n "$DB" ]; then python $3 $DB $2 ${@:4} > ${2%.csv}.txt 2>&1; else echo "no database in $1" > ${2%.csv}.txt; fi
   rm -rf $1
 }
+declare -A PROG=( [bc64]="scripts/prof_fit.py 2048 64 4" [bc256]="scripts/prof_fit.py 2048 256 2" [embed]="scripts/prof_fit.py 2048 64 4 embed" )
 for W in $WHAT; do case $W in
 kt)
-  rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- $CMD1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- python3 bench.py --no-cpu-baseline --in-flight 1 --steps 1 --warmup 0 --repeats 1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
   summarise $OUT/kt1 $OUT/kernel_stats_one_in_flight.csv scripts/rocprof_kernel_stats.py
-  rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline --repeats 1 > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
   summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py ;;
-cfg)   # BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING): kernel-trace summaries
-  rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline -bc 256 --in-flight 2 --steps 2 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
+cfg)
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline -bc 256 --in-flight 2 --steps 2 --repeats 1 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
   summarise $OUT/kt_bc256 $OUT/kernel_stats_bc256.csv scripts/rocprof_kernel_stats.py
-  rocprofv3 --kernel-trace --stats -d $OUT/kt_embed -o run -- python3 bench.py --no-cpu-baseline --coords-embedding --steps 4 > $OUT/bench_embed.json 2> $OUT/kt_embed.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_embed -o run -- python3 bench.py --no-cpu-baseline --coords-embedding --steps 4 --repeats 1 > $OUT/bench_embed.json 2> $OUT/kt_embed.err
   summarise $OUT/kt_embed $OUT/kernel_stats_embed.csv scripts/rocprof_kernel_stats.py ;;
 pmc)
-  for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 500 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o run -- $CMDP > /dev/null 2> $OUT/pmc_$C.err; echo "pmc $C rc=$?" >> $OUT/status.txt
-    summarise $OUT/pmc_$C $OUT/pmc_$C.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply k_build
-  done ;;
+  for CFG in bc64 bc256 embed; do for C in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${CFG}_$C -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/pmc_${CFG}_$C.err; echo "pmc $CFG $C rc=$?" >> $OUT/status.txt
+    summarise $OUT/pmc_${CFG}_$C $OUT/pmc_${CFG}_$C.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply k_build
+  done; done ;;
 sq)
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
-    -d $OUT/sq_a -o run -- $CMDP > /dev/null 2> $OUT/sq_a.err; echo "sq_a rc=$?" >> $OUT/status.txt
-  summarise $OUT/sq_a $OUT/sq_a.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
-  timeout -k 10 500 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM \
-    -d $OUT/sq_b -o run -- $CMDP > /dev/null 2> $OUT/sq_b.err; echo "sq_b rc=$?" >> $OUT/status.txt
-  summarise $OUT/sq_b $OUT/sq_b.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply ;;
+  for CFG in bc64 bc256 embed; do
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
+      -d $OUT/sq_a_$CFG -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/sq_a_$CFG.err; echo "sq_a $CFG rc=$?" >> $OUT/status.txt
+    summarise $OUT/sq_a_$CFG $OUT/sq_a_$CFG.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM \
+      -d $OUT/sq_b_$CFG -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/sq_b_$CFG.err; echo "sq_b $CFG rc=$?" >> $OUT/status.txt
+    summarise $OUT/sq_b_$CFG $OUT/sq_b_$CFG.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
+  done ;;
 esac; done
 ls -la $OUT; cat $OUT/status.txt 2>/dev/null

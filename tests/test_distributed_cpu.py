@@ -65,3 +65,25 @@ def test_bench_gpus_2_starts_two_ranks_by_itself():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"],
                          env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "--gpus 2" in bad.stderr
+
+
+def test_bench_gpus_8_dry_run_has_the_shape_of_configs_3():
+    """BASELINE.json configs[3] -- 64 tiles over 8 ranks -- through the launcher and the exchange (gloo, nothing
+    measured): 64 records, every rank's own clock in the line, the communicator's world size as it reports it; and a
+    rank that fails is named with what it said."""
+    import json
+    import subprocess
+    env = dict(os.environ, LBDRN_BENCH_DRYRUN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "1"],
+                         check=True, env=env, capture_output=True, text=True, timeout=600).stdout
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and len(d["records"]) == 64
+    assert sorted(r[0] for r in d["records"]) == [float(i) for i in range(8, 72)]      # the 64 timed tiles, each once
+    assert d["rank_elapsed_ms"] == [1000.0 * (1 + r) for r in range(8)] and d["max_over_ranks"] == 8.0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"],
+                         env=dict(env, LBDRN_BENCH_DRYRUN_FAIL="2"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "rank 2" in bad.stderr and "simulated failure" in bad.stderr

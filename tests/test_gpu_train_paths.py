@@ -518,5 +518,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    assert r["kernel_us"] > 0 and r["reduce_adam_us"] > 0 and "unaccounted_us" in r
+    assert d["repeats"] == 3 and len(d["ms_per_step_all_repeats"]) == 3 and d["ranks_seen"] == 1 and len(d["rank_elapsed_ms"]) == 1
+    assert min(d["ms_per_step_all_repeats"]) <= d["ms_per_step"] <= max(d["ms_per_step_all_repeats"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert str(c["cores"]) in c["form_B_by_threads"] and c["vectorised_form_B"] == max(c["form_B_by_threads"].values())
