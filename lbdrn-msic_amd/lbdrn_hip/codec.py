@@ -102,22 +102,26 @@ def _fit_stream_pool(dev, n):
         return pool_
 
 
+def alone_streams_fit_queues():
+    """A fit alone in its process uses three streams at a time: the caller's, one fit stream for the background passes,
+    the permutation side stream."""
+    return 3 <= int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+
+
 def overlap_evaluation(dev, alone):
     """Whether a fit's evaluation passes run in the background of its next epoch (fit_device).  A stated policy, not a
     measurement: LBDRN_OVERLAP_EVAL=0 / 1 decides outright (run.sh and sweep.py export 0 when they put several
     processes on one GPU: `alone` only knows about this process); otherwise the passes go to the background when the
-    fit is alone in its process AND every stream the process then uses on this device -- the caller's, the fit
-    streams made so far (at least two), the permutation side stream -- still gets a hardware queue of its own
-    (GPU_MAX_HW_QUEUES, the runtime's default is 4): a background pass that shares a queue with the training chain
-    costs 3x the fit instead of saving 5 % of it (scripts/ab_streamidx.py).  Results are bit-identical either way."""
+    fit is alone in its process AND the three streams it then works on -- the caller's, one fit stream, the
+    permutation side stream -- can each have a hardware queue (GPU_MAX_HW_QUEUES, the runtime's default is 4): a
+    background pass that shares a queue with the training chain costs 3x the fit instead of saving 5 % of it
+    (scripts/ab_streamidx.py).  Results are bit-identical either way."""
     env = os.environ.get("LBDRN_OVERLAP_EVAL")
     if env in ("0", "1"):
         return env == "1"
     if not alone:
         return False
-    with _POOL_LOCK:
-        fit_streams = max(2, len(_FIT_STREAMS.get(dev, [])))
-    return fit_streams + 2 <= int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+    return alone_streams_fit_queues()
 
 
 def _eval_stream(dev, main):
