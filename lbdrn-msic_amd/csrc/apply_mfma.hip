@@ -28,6 +28,9 @@ namespace lbdrn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef LBDRN_APPLY_CHUNK
+#define LBDRN_APPLY_CHUNK 10   // layer-0 steps whose B operands are made in one go (0: four at a time, round 2's loop);
+#endif                         // eval pass on the 8 x 2048^2 tile: 1.845 ms at 0, 1.78 at 10, 1.79-1.82 at 20, 1.87 at 50
 constexpr int APPLY_WAVES = 8;
 constexpr int APPLY_THREADS = APPLY_WAVES * 64;
 constexpr int TILE_W = 64;
@@ -347,7 +350,38 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                 for (int tt = 0; tt < NT; ++tt)
                     acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], b, acc[tt], 0, 0, 0);
             }
+#if LBDRN_APPLY_CHUNK > 0
+            // colour features in chunks of CH steps: the chunk's B operands (window gather, minus centre) are all made
+            // first -- vector and LDS work only --, then its 2 CH MFMAs run with nothing but their A-operand reads
+            // between them: an f32 MFMA and vector work of the SAME wave never overlap, those of the two waves
+            // sharing a SIMD do once their streams are not both a fine mix of the two (scripts/pipe_probe.hip)
+            constexpr int CH = LBDRN_APPLY_CHUNK;
+            int s4 = P;
+            for (; s4 + CH <= p.S0; s4 += CH) {
+                float bq[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int kk = 2 * (s4 + u - P) + h;
+                    const int2 e = *reinterpret_cast<const int2*>(ktab + 2 * kk);
+                    const float nb = tile[pixbase + e.x];
+                    const float ct = tile[pixbase + e.y];
+                    bq[u] = rel ? nb - ct : nb;  // minus centre, LBDRNdataset.py:126-128
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    float a[NT];
+                    load_a<NT>(w0, (s4 + u) * 64 + lane, a);
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], bq[u], acc[tt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; s4 < p.S0; s4 += 4) {
+#else
             for (int s4 = P; s4 < p.S0; s4 += 4) {  // colour features, four MFMA steps per trip
+#endif
                 float bq[4];
                 float aq[4][NT];
 #pragma unroll
