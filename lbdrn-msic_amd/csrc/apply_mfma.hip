@@ -29,8 +29,8 @@ namespace lbdrn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifndef LBDRN_APPLY_CHUNK
-#define LBDRN_APPLY_CHUNK 10   // layer-0 steps whose B operands are made in one go (0: four at a time, round 2's loop);
-#endif                         // eval pass on the 8 x 2048^2 tile: 1.845 ms at 0, 1.78 at 10, 1.79-1.82 at 20, 1.87 at 50
+#define LBDRN_APPLY_CHUNK 20   // layer-0 steps whose B operands are made in one go, a multiple of 4 (0: four at a time, round
+#endif                         // 2's loop); eval pass on the 8 x 2048^2 tile: 1.845 ms at 0, 1.79-1.82 at 20, 1.87 at 52
 constexpr int APPLY_WAVES = 8;
 constexpr int APPLY_THREADS = APPLY_WAVES * 64;
 constexpr int TILE_W = 64;
@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             // between them: an f32 MFMA and vector work of the SAME wave never overlap, those of the two waves
             // sharing a SIMD do once their streams are not both a fine mix of the two (scripts/pipe_probe.hip)
             constexpr int CH = LBDRN_APPLY_CHUNK;
+            static_assert(CH % 4 == 0, "the steps left behind the chunks are taken four at a time");
             int s4 = P;
             for (; s4 + CH <= p.S0; s4 += CH) {
                 float bq[CH];
