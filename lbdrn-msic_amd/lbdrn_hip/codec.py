@@ -315,9 +315,10 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     ~5 us -> train ...), so several independent fits progress together.  How they share the chip is `group`:
     fits of one raster shape are taken `group` at a time and step side by side in ONE launch per minibatch
     (fit_group: 2 x 128 workgroups = every CU, deterministically), and in_flight // group such groups run on their
-    own streams and host threads, one training while the other reduces.  group=None: LBDRN_FIT_GROUP, else 2 when at
-    least four fits are in flight, else 1 (every fit its own chain: round 2's scheme, 128-workgroup launches of
-    independent chains that pair up on the chip only by chance).  Images are independent fits and
+    own streams and host threads, one training while the other reduces.  group=None: LBDRN_FIT_GROUP, else 1 (every fit
+    its own chain of 128-workgroup launches: measured on 8 x 2048^2 tiles, ms per tile at group : in flight --
+    1:4 72.8, 2:4 75.5, 2:6 72.3, 3:6 75.6; groups halve the host's launches and tie at six in flight, so the default
+    stays the simple one).  Images are independent fits and
     every fit seeds the generator itself (`seed`, what each encode.py invocation does, ref encode.py:200-205), so
     results are bit-identical to fitting them one after another, whatever the grouping.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
@@ -326,7 +327,7 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     if in_flight is None:
         in_flight = 4
     if group is None:
-        group = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (2 if in_flight >= 4 else 1)
+        group = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or 1
     group = max(1, min(group, in_flight, ops.train_group_max()))
     if draws is not None:
         seed = None
