@@ -38,7 +38,9 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=None,
-                   help="timed tiles per GPU (default 8: at --gpus 8 the 64-tile job of BASELINE.json configs[3])")
+                   help="timed tiles per GPU (default: 16 on one GPU -- four rounds of the four fits in flight, the first of "
+                        "which start in lockstep -- and 8 with --gpus N > 1: at 8 GPUs the 64-tile job of BASELINE.json "
+                        "configs[3])")
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--height", type=int, default=2048)
     p.add_argument("--width", type=int, default=2048)
@@ -62,7 +64,7 @@ def parse():
                    help="epochs of the recipe the CPU baseline runs on its crop (scaled to the full recipe)")
     a = p.parse_args()
     if a.steps is None:
-        a.steps = 8
+        a.steps = 16 if a.gpus == 1 else 8
     return a
 
 
