@@ -124,8 +124,9 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     fwd, step = flops_per_pixel(geom.F, net.bc, net.C, net.nl)
     ws = ops.ApplyWorkspace(geom, net, img_d.device)
     p = fit.best_params
-    ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws)
-    t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws), stream, 3)
+    fast = codec.fast_evaluation()    # the arithmetic the fit's own evaluation passes ran in
+    ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast)
+    t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast), stream, 3)
     perm = torch.randperm(N, device=img_d.device)
     pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
     tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path)
@@ -167,7 +168,9 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
                 "train_step_pair_tflops": round(step * N / (t_epoch * 1e-3) / 1e12, 3),
                 "apply_pass_ms": round(t_eval, 3), "apply_tflops": round(fwd * N / (t_eval * 1e-3) / 1e12, 3),
                 "apply_frac": round(fwd * N / (t_eval * 1e-3) / 1e12 / peak, 4),
-                "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1)})
+                "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1),
+                "apply_pass": "the per-epoch evaluation pass as the fit runs it: " +
+                              ("LBDRN_EVAL_FAST (tolerance arithmetic)" if fast else "canonical arithmetic")})
     if fused:
         # the kernel holds half of the chip (two fits' steps run side by side): the same rate against the peak of
         # the CUs it occupies

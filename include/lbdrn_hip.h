@@ -110,6 +110,14 @@ int lbdrn_decode_fused(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t
  * workgroups, for running on a second stream beside a fit's training steps (which hold the other half of the CUs).
  * Same *sse bit for bit. */
 #define LBDRN_EVAL_BACKGROUND 0x200
+/* path may also carry LBDRN_EVAL_FAST: the pass is the reference's PER-EPOCH evaluation (encode.py:104-117), whose
+ * result only ranks the epochs -- an encode-time float, held to the 1e-5 relative tolerance like the training loss, not
+ * to a bit pattern.  With the flag the fused kernels take sin and the sigmoid from the hardware's transcendental
+ * instructions behind a compensated reduction (4.5e-7 absolute per activation, the training step's arithmetic) instead
+ * of the canonical polynomials the decode kernels must use: *sse within 1e-6 relative of the flagless call (tested),
+ * the pass 20 % shorter.  Still a fixed summation order: bitwise reproducible, same sum on any launch shape.  The
+ * generic path ignores the flag. */
+#define LBDRN_EVAL_FAST 0x400
 int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
                    const uint16_t *msb, const float *params, double *sse, void *workspace,
                    size_t workspace_bytes, int32_t path, void *stream);

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256)
 
 // ------------------------------------------------------------------ the fused kernel
 
-enum ApplyMode { MODE_DECODE = 0, MODE_EVAL = 1 };
+enum ApplyMode { MODE_DECODE = 0, MODE_EVAL = 1, MODE_EVAL_FAST = 2 };   // _FAST: the evaluation pass in the tolerance arithmetic (lbdrn_math.hpp)
 
 struct ApplyArgs {
     lbdrn_geom g;
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hid[tt][r] = siren_act(acc[tt][r]);
+                for (int r = 0; r < 16; ++r) hid[tt][r] = MODE == MODE_EVAL_FAST ? fast_sin(30.0f * acc[tt][r]) : siren_act(acc[tt][r]);
             ASTAMP(2);  // sin
             // ---- hidden layers 1..nl-1: B operand = previous activations, straight from registers
             for (int l = 1; l < A.net.nl; ++l) {
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) hid[tt][r] = siren_act(acc[tt][r]);
+                    for (int r = 0; r < 16; ++r) hid[tt][r] = MODE == MODE_EVAL_FAST ? fast_sin(30.0f * acc[tt][r]) : siren_act(acc[tt][r]);
             }
             ASTAMP(3);  // hidden layers incl. their sin
             // ---- last layer: rows = channels
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             for (int r = 0; r < 16; ++r) {
                 const int ch = acc_row(r, h);
                 if (r < nreg && ch < C && inside) {
-                    float yv = canon_sigmoid(o[r]);
+                    float yv = MODE == MODE_EVAL_FAST ? fast_sigmoid(o[r]) : canon_sigmoid(o[r]);
                     if (MODE == MODE_DECODE) {
                         float rr = __builtin_rintf(yv * scale);  // torch.round, decode.py:131
                         int base = (int)pre[r] << g.K;             // decode.py:134
@@ -467,7 +467,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             ASTAMP(5);  // epilogue
         }
     }
-    if (MODE == MODE_EVAL) {
+    if (MODE != MODE_DECODE) {
         __syncthreads();
         double* red = reinterpret_cast<double*>(lds + ((p.off_rowt + 3) & ~3));  // the per-tile regions: consumed
         red[tid] = sse;
@@ -577,7 +577,8 @@ static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const
     if (!wstamp_buf) LBDRN_HIP_TRY(hipMalloc(&wstamp_buf, 1024 * 8 * sizeof(unsigned long long)));
     A.stamps = wstamp_buf;
 #endif
-    int rc = mode == MODE_DECODE ? dispatch_wapply<MODE_DECODE>(A, grid, s) : dispatch_wapply<MODE_EVAL>(A, grid, s);
+    int rc = mode == MODE_DECODE ? dispatch_wapply<MODE_DECODE>(A, grid, s)
+           : mode == MODE_EVAL_FAST ? dispatch_wapply<MODE_EVAL_FAST>(A, grid, s) : dispatch_wapply<MODE_EVAL>(A, grid, s);
     if (rc) return rc;
     if (mode != MODE_DECODE) {
         k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, A.nvirt, sse);
@@ -636,9 +637,13 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
            : A.p.NT == 2 ? launch_apply<2, MODE_DECODE>(A, grid, s)
                          : launch_apply<4, MODE_DECODE>(A, grid, s);
     } else {
-        rc = A.p.NT == 1 ? launch_apply<1, MODE_EVAL>(A, grid, s)
-           : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s)
-                         : launch_apply<4, MODE_EVAL>(A, grid, s);
+        rc = mode == MODE_EVAL_FAST
+                 ? (A.p.NT == 1 ? launch_apply<1, MODE_EVAL_FAST>(A, grid, s)
+                    : A.p.NT == 2 ? launch_apply<2, MODE_EVAL_FAST>(A, grid, s)
+                                  : launch_apply<4, MODE_EVAL_FAST>(A, grid, s))
+                 : (A.p.NT == 1 ? launch_apply<1, MODE_EVAL>(A, grid, s)
+                    : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s)
+                                  : launch_apply<4, MODE_EVAL>(A, grid, s));
         if (rc) return rc;
         k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, A.nvirt, sse);
         LBDRN_LAUNCH_CHECK();
@@ -666,9 +671,10 @@ int mfma_decode(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* msb, 
 
 int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                   const uint16_t* msb, const float* params, double* sse, void* ws, size_t ws_bytes,
-                  bool background, hipStream_t s)
+                  bool background, bool fast, hipStream_t s)
 {
-    return run_apply(g, net, MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes, background, s);
+    return run_apply(g, net, fast ? MODE_EVAL_FAST : MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes,
+                     background, s);
 }
 
 }  // namespace lbdrn

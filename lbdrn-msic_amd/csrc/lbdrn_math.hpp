@@ -119,6 +119,33 @@ LBDRN_DEV float canon_sigmoid(float z)
 // Sine(w0=30): ref LBDRNmodel.py:13 -- the product 30*z is rounded to float32 first
 LBDRN_DEV float siren_act(float z) { return canon_sin(30.0f * z); }
 
+// ---- arithmetic of the passes that are held to a tolerance (north_star: encode-time float loss within 1e-5 relative),
+// not to a bit pattern: the training step and the per-epoch evaluation pass that picks the best epoch.
+// sin / cos from the hardware's v_sin_f32 / v_cos_f32 (arguments in revolutions, quarter rate) behind a compensated
+// reduction: x / (2 pi) as a float32 product, plus that product's exact residual and x times the low half of 1 / (2 pi).
+// 4.5e-7 absolute over the range the activations see (scripts/sin_probe.hip: the intrinsic error of the instructions).
+constexpr float kRevHi = 0x1.45f306p-3f, kRevLo = 0x1.b93910p-28f;   // 1 / (2 pi) = kRevHi + kRevLo
+LBDRN_DEV float fast_rev(float x)
+{
+    const float rev = x * kRevHi;
+    const float res = fma_(x, kRevHi, -rev);                 // exact
+    return __builtin_amdgcn_fractf(rev) + fma_(x, kRevLo, res);
+}
+LBDRN_DEV float fast_sin(float x) { return __builtin_amdgcn_sinf(fast_rev(x)); }
+LBDRN_DEV void fast_sincos(float x, float& sn, float& cs)
+{
+    const float f = fast_rev(x);
+    sn = __builtin_amdgcn_sinf(f);
+    cs = __builtin_amdgcn_cosf(f);
+}
+// sigmoid by v_exp + v_rcp, ~1e-7 relative
+LBDRN_DEV float fast_sigmoid(float z)
+{
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * __builtin_fabsf(z));   // e^-|z|
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return z >= 0.0f ? r : e * r;
+}
+
 // numpy.pad(mode="reflect") index map (ref LBDRNdataset.py:120-123)
 LBDRN_DEV int reflect_idx(int i, int n)
 {

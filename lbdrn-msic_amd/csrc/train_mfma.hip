@@ -965,31 +965,15 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 // Three workgroup barriers: rows + layer-0 weights in LDS; layer 0 done (its weights' space is reused); dz complete.
 // A minibatch of 8192 rows is 128 workgroups: the gradient slab exchange is half the tile kernel's, and two fits in
 // flight on one GPU run side by side on disjoint halves of the chip instead of taking turns.
-// fast sigmoid for the training step (a tolerance contract, 1e-5 on the loss): v_exp + v_rcp, ~1e-7 relative
-__device__ __forceinline__ float train_sigmoid(float z)
-{
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * __builtin_fabsf(z));   // e^-|z|
-    const float r = __builtin_amdgcn_rcpf(1.0f + e);
-    return z >= 0.0f ? r : e * r;
-}
-
-// sin and cos of the training step (a tolerance contract like the sigmoid above; the decode / evaluation kernels keep
-// the canonical polynomial sin of lbdrn_math.hpp): the hardware's v_sin_f32 / v_cos_f32 -- arguments in revolutions,
-// quarter rate -- behind a compensated reduction: x / (2 pi) as a float32 product, plus that product's exact residual
-// and x times the low half of 1 / (2 pi).  4.5e-7 absolute over the range the activations see (scripts/sin_probe.hip:
-// the intrinsic error of the instructions), five full-rate and two quarter-rate instructions against canon_sincos's 31.
+// sigmoid, sin and cos of the training step: a tolerance contract (1e-5 relative on the loss), so the hardware's
+// transcendentals behind a compensated reduction (lbdrn_math.hpp: fast_sigmoid, fast_sincos; 4.5e-7 absolute against 1e-7
+// for the canonical polynomials, 7 instructions against 31); the decode kernels keep the canonical arithmetic.
+// -DLBDRN_TRAIN_CANON_SINCOS puts the canonical pair back (A/B).
+__device__ __forceinline__ float train_sigmoid(float z) { return fast_sigmoid(z); }
 #ifdef LBDRN_TRAIN_CANON_SINCOS
 __device__ __forceinline__ void train_sincos(float x, float& sn, float& cs) { canon_sincos(x, sn, cs); }
 #else
-__device__ __forceinline__ void train_sincos(float x, float& sn, float& cs)
-{
-    constexpr float kHi = 0x1.45f306p-3f, kLo = 0x1.b93910p-28f;   // 1 / (2 pi) = kHi + kLo
-    const float rev = x * kHi;
-    const float res = __builtin_fmaf(x, kHi, -rev);                 // exact
-    const float f = __builtin_amdgcn_fractf(rev) + __builtin_fmaf(x, kLo, res);
-    sn = __builtin_amdgcn_sinf(f);
-    cs = __builtin_amdgcn_cosf(f);
-}
+__device__ __forceinline__ void train_sincos(float x, float& sn, float& cs) { fast_sincos(x, sn, cs); }
 #endif
 
 // sum over the 64 lanes, same order every time, no LDS: rows of 16 by DPP shifts, then the four row totals

@@ -102,6 +102,15 @@ def _fit_stream_pool(dev, n):
         return pool_
 
 
+def fast_evaluation():
+    """The per-epoch evaluation passes of a fit rank its epochs (encode.py:104-117): an encode-time float under the
+    1e-5 tolerance contract like the training loss, so they run in the training step's arithmetic (LBDRN_EVAL_FAST:
+    hardware sin / exp behind a compensated reduction, 4.5e-7 per activation; the sum within 1e-6 relative of the
+    canonical one, 20 % less time per pass).  LBDRN_EVAL_CANONICAL=1 keeps them on the decode kernels' canonical
+    arithmetic (bit for bit the oracle's sum).  Decoding is always canonical."""
+    return os.environ.get("LBDRN_EVAL_CANONICAL") != "1"
+
+
 def alone_streams_fit_queues():
     """A fit alone in its process uses three streams at a time: the caller's, one fit stream for the background passes,
     the permutation side stream."""
@@ -206,7 +215,8 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
                     side.wait_stream(main)
                 with torch.cuda.stream(side if side is not None else main):
                     background = side is not None and e != epochs      # nothing trains beside the last pass
-                    sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background)   # a9
+                    sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background,
+                                       fast=fast_evaluation())   # a9
                     mses[k:k + 1].copy_((sse / float(N * C)).float())
                 out.evaluated.append(e)
     finally:
@@ -286,7 +296,7 @@ def fit_group(imgs_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
             k = eval_epochs.index(e)
             for f, out in zip(st, outs):
                 f["snaps"][k].copy_(f["params"])
-                sse = ops.eval_sse(f["geom"], net, f["img"], f["msb"], f["snaps"][k], path, f["aws"])   # a9
+                sse = ops.eval_sse(f["geom"], net, f["img"], f["msb"], f["snaps"][k], path, f["aws"], fast=fast_evaluation())   # a9
                 f["mses"][k:k + 1].copy_((sse / float(N * C)).float())
                 out.evaluated.append(e)
     for f, out in zip(st, outs):

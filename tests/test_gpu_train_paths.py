@@ -411,6 +411,42 @@ def test_background_evaluation_pass_is_the_same_sum(dev, shape):
     assert torch.equal(fits[0].mse_log, fits[1].mse_log)
 
 
+def test_fast_evaluation_pass_ranks_epochs_like_the_canonical_one(golden, dev):
+    """LBDRN_EVAL_FAST: the per-epoch evaluation in the training step's arithmetic.  Its float64 sum is within 1e-6
+    relative of the canonical pass (untrained weights, the trained weights of a learnable image, the wide-argument
+    weights of the "scaled" raster; bc = 64 and 256, with and without the positional embedding), it is reproducible
+    bit for bit, the same on a background launch, and a fit that ranks its epochs with it picks the same epoch and
+    ends on the same weights as one that ranks them canonically."""
+    for tag in ("bc64", "bc256", "embed", "scaled"):
+        G = golden["rasters_learn_" + tag]
+        img, K, D, bc, nl = G["img"], int(G["K"]), int(G["D"]), int(G["bc"]), int(G["nl"])
+        f = G["flags"]
+        cfg = FeatCfg(bool(f[0]), bool(f[1]), 1.4, 12, bool(f[2]), bool(f[3]))
+        C, H, W = img.shape
+        img_d = ops.to_device_u16(img, dev)
+        msb_d, mx = ops.split_bits(img_d, K)
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(cfg.feature_dim(C, D), bc, C, nl)
+        p = torch.from_numpy(G["params"]).to(dev)
+        canon = float(ops.eval_sse(geom, net, img_d, msb_d, p).item())
+        fast = [float(ops.eval_sse(geom, net, img_d, msb_d, p, fast=True, background=b).item()) for b in (False, False, True)]
+        assert fast[0] == fast[1] == fast[2], tag
+        assert abs(fast[0] - canon) <= 1e-6 * canon, (tag, fast[0], canon)
+    img_d = ops.to_device_u16(golden["rasters_learn_bc64"]["img"], dev)
+    fits = []
+    for canonical in ("0", "1"):
+        os.environ["LBDRN_EVAL_CANONICAL"] = canonical
+        try:
+            torch.manual_seed(19920517)
+            fits.append(codec.fit_device(img_d, 5, 2, 64, 2, 1e-3, 8192, 12))
+        finally:
+            os.environ.pop("LBDRN_EVAL_CANONICAL", None)
+    a, b = fits
+    assert torch.equal(a.best_params.view(torch.int32), b.best_params.view(torch.int32))
+    assert torch.equal(a.mse_log[:, 1], b.mse_log[:, 1])
+    np.testing.assert_allclose(a.mse_log[:, 0].cpu().numpy(), b.mse_log[:, 0].cpu().numpy(), rtol=1e-6)
+
+
 def test_fit_learns_what_the_torch_port_learns(golden, dev):
     """A fit that has something to learn: the smooth 8 x 128 x 128 image of the learnable reference rasters
     (tests/golden/make_golden_round3.py; its low bits follow from the neighbours' high bits), 90 epochs = 180 Adam steps,

@@ -24,6 +24,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert (consts["LBDRN_PATH_AUTO"], consts["LBDRN_PATH_GENERIC"], consts["LBDRN_PATH_MFMA"]) == \
         (_lib.PATH_AUTO, _lib.PATH_GENERIC, _lib.PATH_MFMA)
     assert consts["LBDRN_EVAL_BACKGROUND"] == _lib.EVAL_BACKGROUND and _lib.EVAL_BACKGROUND > _lib.PATH_MFMA
+    assert consts["LBDRN_EVAL_FAST"] == _lib.EVAL_FAST and not (_lib.EVAL_FAST & (_lib.EVAL_BACKGROUND | 3))
 
 
 def test_geometry_helpers_without_device():
