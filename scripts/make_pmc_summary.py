@@ -34,9 +34,10 @@ def pick(table, kernel_sub, counter):
 for f in sorted(os.listdir(src)):
     if f.endswith((".csv", ".json")) and not f.startswith("."):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
-KERNELS = {"bc64": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 1>"},
-           "bc256": {"train": "k_train_wide", "reduce": "k_reduce_adam", "apply_eval": "k_apply_wide<16, 2, 1>"},
-           "embed": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 1>"}}
+# (apply_eval: the evaluation pass as a fit runs it -- MODE_EVAL_FAST = 2; the canonical MODE_EVAL = 1 pass where a run used it)
+KERNELS = {"bc64": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+           "bc256": {"train": "k_train_wide", "reduce": "k_reduce_adam", "apply_eval": "k_apply_wide<16, 2, 2>", "apply_decode": "k_apply_wide<16, 2, 0>"},
+           "embed": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"}}
 out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of scripts/prof_fit.py per "
                  f"configuration (one fit at a time: scripts/profile_round.sh {tag}); per-kernel means in profiles/{tag}_pmc_*.csv and "
                  f"profiles/{tag}_sq_*.csv.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half of a wide coalesced read), "
