@@ -62,28 +62,13 @@ constexpr int RED_SLICES = LBDRN_RED_SLICES;   // workgroup slices per reduce bl
 constexpr int RED_LANES = 256 / RED_SLICES;  // float4 lanes per reduce block
 constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample tile st = 0..1)
 
-// ---- the wave-local step (k_train_wave, below): 64 samples per workgroup, 4 waves, 16 samples per wave
+// ---- the wave-local steps (k_train_stream, k_train_wide): 64 samples per workgroup, 16 samples per compute wave
 constexpr int WB = 64;            // samples per workgroup
 constexpr int WAVE_THREADS = 256;
-constexpr int WHP = 80;           // [sample][64 units] row pitch.  All pitches of this kernel are = 16 (mod 32) floats:
-constexpr int WOP = 16;           //   the weight-gradient operands are read one float per lane, lanes 0-15 along a row
-                                  //   and lane quarters one row apart, so two quarters (one ds_read_b32 group) cover
-                                  //   all 32 banks
-__host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ == 32 ? 144 : LQ == 52 ? 208 : 272; }
+constexpr int WOP = 16;           // k_train_wide: [sample][16 channel slots] pitch of dz_out
+__host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ == 32 ? 144 : LQ == 52 ? 208 : 272; }   // k_train_wide: row pitch, matrix = LDS
 constexpr int TBC_W = 64;
-constexpr int WPT = 68;   // [unit][64 samples] pitch of the transposed dz copies (16-byte rows, quarters 16 banks apart)
-
-__host__ __device__ constexpr int wave_region_floats(int NL)   // H1.. | dz^T | dz_out | loss partials
-{
-    return (NL - 1) * WB * WHP + NL * TBC_W * WPT + WB * WOP + 4 + 64;   // .. | 4 loss partials | [4 waves][16] output-bias partials
-}
-__host__ __device__ constexpr int wave_lds_total(int LQ, int NL)
-{
-    const int stage = LQ * 256;   // the layer-0 fragments: 4 tiles x LQ/4 blocks x 256 floats
-    const int region = wave_region_floats(NL);
-    return WB * wave_xp(LQ) + WB * WHP + (stage > region ? stage : region);
-}
-
+constexpr int WPT = 68;   // [unit][64 samples] pitch of the transposed dz copies (16-byte rows)
 
 struct TrainPlan {
     int LQ;                    // layer-0 quarter length = MFMA steps of layer 0 (F <= 4*LQ)
@@ -93,7 +78,7 @@ struct TrainPlan {
     int64_t NP;
     int64_t offW[5], offB[5];  // canonical parameter offsets per layer (index nl = last layer)
     int pk_w0, pk_wh, pk_wl, pack_floats;  // fragment-order buffer (floats)
-    int wave;                  // 2: k_train_stream, 1: k_train_wave, 0: the tile kernel (fragment orders differ, see frag_pos)
+    int wave;                  // 2: k_train_stream, 0: the tile kernel (fragment orders differ, see frag_pos)
     int pk_wht, pk_wlt;        // wave-local kernel: W_l^T and W_last^T fragments for the backward products
     int w_dp, w_df;            // 64 / (RP/4) and 64 % (RP/4): chunk walk of the row copy
     int wave_lds_floats;
@@ -101,16 +86,16 @@ struct TrainPlan {
     int lds_x, lds_xt, lds_h, lds_ht, lds_z, lds_zt, lds_zo, lds_zot, lds_pix, lds_red, lds_floats;
 };
 
-// which fused step runs a shape this file supports: 2 = k_train_stream (default), 1 = k_train_wave (round 2's kernel),
-// 0 = the 8-wave tile kernel k_train_mfma (nl = 3).  LBDRN_TRAIN_KERNEL = "tile" / "wave" forces an older one for A/B
-// measurements; it is read ONCE per process (the choice fixes the row-matrix layout that lbdrn_train_prepare builds
-// and lbdrn_train_epoch reads: it must not change between the two).
+// which fused step runs a shape this file supports: 2 = k_train_stream (default), 0 = the 8-wave tile kernel
+// k_train_mfma (nl = 3, and anything LBDRN_TRAIN_KERNEL=tile asks for: A/B measurements).  The variable is read ONCE per
+// process (the choice fixes the row-matrix layout that lbdrn_train_prepare builds and lbdrn_train_epoch reads: it must not
+// change between the two).
 static int train_kernel_choice()
 {
     static const int choice = [] {
         const char* e = getenv("LBDRN_TRAIN_KERNEL");
         if (!e) return 2;
-        return e[0] == 't' ? 0 : e[0] == 'w' ? 1 : 2;
+        return e[0] == 't' ? 0 : 2;
     }();
     return choice;
 }
@@ -129,7 +114,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     if (kind == 2) {   // the streamed step: features in 4 LQ slots, labels in a group of their own
         for (int lq : {16, 32, 52, 64})
             if (net.F <= 4 * lq) { p.LQ = lq; break; }
-        if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 1; p.LQ = 0; }
+        if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 0; p.LQ = 0; }
     }
     if (kind != 2)
         for (int lq : {16, 32, 52, 64})
@@ -159,19 +144,6 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     if (kind == 2) {
         p.RP = stream_rp(p.LQ);   // the matrix in the order layer 0 eats it (train_stream.inc)
         p.wave_lds_floats = stream_lds_total(p.LQ, net.nl);
-    } else if (kind == 1) {   // wave-local kernel: X [64][XP] + H, Z [nl][64][80] + Zo [64][16] + 4 doubles
-        const int xp = wave_xp(p.LQ);
-        p.wave_lds_floats = WB * xp + WB * WHP + std::max(p.LQ * 256, wave_region_floats(net.nl));
-        if (!(p.RP <= xp && 16 * p.NT0 <= xp && (size_t)p.wave_lds_floats * 4 <= 160 * 1024)) kind = 0;
-        // the wave-local kernel brings its rows in by LDS-DMA, which wants the matrix row pitch equal to the LDS row
-        // pitch (a wave's 16 rows are then one lane-linear piece): the row matrix is padded to it (config 1: 208 = 208;
-        // positional embedding, F = 250: 260 -> 272 floats, 4.6 % more rows traffic for a prologue without registers)
-        if (kind == 1) {
-            p.RP = xp;
-            const int rp4 = p.RP / 4;
-            p.w_dp = 64 / rp4;
-            p.w_df = 64 % rp4;
-        }
     }
     p.wave = kind;
     int s = 4 * p.NT0 * 256;
@@ -944,27 +916,19 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 #endif
 }
 
-// ------------------------------------------------------------------ the wave-local step
+// ------------------------------------------------------------------ the wave-local steps
 //
-// k_train_wave: 64 samples per workgroup, 4 waves (one per SIMD), each wave owns 16 samples from the row copy to
-// dL/dz of the first layer WITHOUT exchanging data with another wave: a layer's accumulators
-// (v_mfma_f32_16x16x4_f32: lane (i, q), tile t, register r = unit 16t+4q+r of sample i) are exactly the B operand of
-// the next product when that product walks k = 16t+4q+r (frag_pos, p.wave), forward and backward alike.  So the whole
-// forward + backpropagation is one dependency-free stream per wave -- four independent accumulator tiles per layer
-// (the 40-cycle dependent latency of the 32-cycle MFMA never shows), no LDS round trip between layers.
-//
-// What bounds a step on a CU is not the matrix pipe but the two narrow paths beside it: the vector-memory path
-// (64 B/clk per CU whether a line hits L1 or not) and the issue rate of LDS instructions of a single wave.  Hence:
-//  * the layer-0 weights (53 of the 93 KB a wave multiplies by) are fetched ONCE per workgroup, straight into LDS
-//    (global_load_lds, each wave a quarter), over the regions that hold H1 / dz^T later, and read from there as
-//    fragments (ds_read_b128, 256 B/clk); the small matrices of the other products come L2 -> VGPR while layer 0 runs;
-//  * weight gradients sum over the 64 samples of the workgroup: dz is parked TRANSPOSED ([unit][sample], samples
-//    permuted so that lane quarter q finds its 16 samples in one 64-byte piece), so the A operands of a whole layer
-//    (4 tiles x 16 steps) are 16 ds_read_b128; each wave then takes every fourth 16-column strip of the inputs and
-//    multiplies all four unit tiles against it (64 MFMAs per 16 one-float reads of the row-major inputs).
-// Three workgroup barriers: rows + layer-0 weights in LDS; layer 0 done (its weights' space is reused); dz complete.
-// A minibatch of 8192 rows is 128 workgroups: the gradient slab exchange is half the tile kernel's, and two fits in
-// flight on one GPU run side by side on disjoint halves of the chip instead of taking turns.
+// k_train_stream (train_stream.inc; bc = 64) and k_train_wide (train_wide.inc; bc = 128 / 256): 64 samples per workgroup,
+// 4 compute waves (one per SIMD), each wave owns 16 samples from the row copy to dL/dz of the first layer WITHOUT
+// exchanging data with another wave: a layer's accumulators (v_mfma_f32_16x16x4_f32: lane (i, q), tile t, register r =
+// unit 16t+4q+r of sample i) are exactly the B operand of the next product when that product walks k = 16t+4q+r
+// (frag_pos, p.wave), forward and backward alike.  So the whole forward + backpropagation is one dependency-free stream
+// per wave -- four independent accumulator tiles per layer (the 40-cycle dependent latency of the 32-cycle MFMA never
+// shows), no LDS round trip between layers.  Weight gradients sum over the 64 samples of the workgroup: dz is parked
+// transposed in LDS, each wave takes every fourth 16-column strip of the inputs against all four unit tiles.  A
+// minibatch of 8192 rows is 128 workgroups, one per CU on half of the chip: two fits in flight run side by side.
+// (Round 2's first kernel of this family, k_train_wave, waited for all of its rows and layer-0 fragments before its
+// first MFMA; k_train_stream replaced it in round 3 -- the history keeps it.)
 // sigmoid, sin and cos of the training step: a tolerance contract (1e-5 relative on the loss), so the hardware's
 // transcendentals behind a compensated reduction (lbdrn_math.hpp: fast_sigmoid, fast_sincos; 4.5e-7 absolute against 1e-7
 // for the canonical polynomials, 7 instructions against 31); the decode kernels keep the canonical arithmetic.
@@ -994,437 +958,6 @@ __device__ __forceinline__ float wave_sum(float x)
     const float a = __int_as_float(__builtin_amdgcn_readlane(xi, 15)), b = __int_as_float(__builtin_amdgcn_readlane(xi, 31));
     const float c = __int_as_float(__builtin_amdgcn_readlane(xi, 47)), d = __int_as_float(__builtin_amdgcn_readlane(xi, 63));
     return (a + b) + (c + d);
-}
-
-template <int LQ, int NL>
-__global__ void __launch_bounds__(WAVE_THREADS, 1) k_train_wave(TrainArgs A)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const TrainPlan& p = A.p;
-    const TrainFit& Ft = A.fit[0];
-    constexpr int XP = wave_xp(LQ), HP = WHP, OP = WOP, PT = WPT, G0 = LQ / 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and the compiler should know it
-    const int i = lane & 15, q = lane >> 4;
-    const int C = A.net.C, F = A.net.F;
-    float* Xs = lds;                        // [64][XP]  features | labels, row-major
-    float* H0 = Xs + WB * XP;               // [64][HP]  activations of layer 0
-    float* R = H0 + WB * HP;                // region shared in time: layer-0 fragments, then
-    float* Hx = R;                          //   [NL-1][64][HP] activations of layers 1..
-    float* ZT = Hx + (NL - 1) * WB * HP;    //   [NL][64 units][PT] dL/dz transposed, column = 16 (s & 3) + (s >> 2)
-    float* Zo = ZT + NL * TBC * PT;         //   [64][OP]  dL/dz of the output layer
-    float* red = Zo + WB * OP;              //   [4] loss partials, then [4 waves][16 slots] output-bias partials
-    const float* W0s = R;                   // [4 tiles][G0 blocks][64 lanes][4]
-    auto Hl = [&](int l) -> float* { return l == 0 ? H0 : Hx + (size_t)(l - 1) * WB * HP; };
-    const int wg = blockIdx.x, first = wg * WB;
-    const int nvalid = min(WB, A.batch_n - first);
-    const int srow = 16 * w + i;            // this lane's sample (column of every forward / backward tile)
-    float* slab = Ft.slabs + (size_t)wg * p.slab_floats;
-    const WtBuf slabw(slab, (size_t)p.slab_floats * 4);
-#ifdef LBDRN_TRAIN_STAMPS
-    unsigned long long stamp[16] = {};
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[14])::"memory");
-#endif
-    STAMP(0);
-
-    // which rows: lane j (mod 16) fetches the pixel index of row j of this wave; the row copy below picks its
-    // rows up by shuffle (a load per chunk would chain every row request behind an index load: loads retire in order)
-    // (rows past the end repeat the last row: finite values; the raw index is clamped where it is used, so that
-    //  nothing here waits for the load)
-    auto clamp_pix = [&](int64_t pix) -> int { return (int)(pix < 0 ? 0 : (pix >= A.npix ? A.npix - 1 : pix)); };
-    const int64_t raw_mine = A.stage_in == nullptr ? Ft.perm[min(first + 16 * w + i, A.batch_n - 1)] : 0;
-    // biases: tiny, and the first MFMA of every layer starts from them -- ahead of every other request
-    f32x4 bias[NL][4];
-#pragma unroll
-    for (int l = 0; l < NL; ++l)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float4 b4 = *reinterpret_cast<const float4*>(Ft.params + p.offB[l] + 16 * t + 4 * q);
-            bias[l][t][0] = b4.x; bias[l][t][1] = b4.y; bias[l][t][2] = b4.z; bias[l][t][3] = b4.w;
-        }
-    f32x4 bias_last;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bias_last[r] = (4 * q + r) < C ? Ft.params[p.offB[NL] + 4 * q + r] : 0.0f;
-
-    // ---- rows: the wave copies its own 16 rows (16 * RP/4 chunks of 16 B, chunk c = lane + 64 u), gathered from the
-    //      [N][RP] row matrix by pixel index (a staging buffer filled one launch ahead, as the tile kernel keeps, buys
-    //      nothing here: with every request of the prologue in flight at once the gather lands as fast as a contiguous
-    //      read -- measured -- and it costs a gather, a store and a read of 6.8 MB per step).  The matrix row pitch
-    //      equals the LDS row pitch, so the 16 rows are one contiguous piece in LDS too and go there by LDS-DMA like the
-    //      weights: no registers, no ds_write, and every request of the prologue in flight at once (a ds_write behind an
-    //      LDS-DMA waits for vmcnt(0)).
-    constexpr int NLD = (16 * (XP / 4) + 63) / 64;
-    const int rp4 = p.RP >> 2, nchunk = 16 * rp4;
-    const int row0 = lane / rp4, col0 = lane - row0 * rp4;
-#define LBDRN_LDS_DMA(gptr, lptr) \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-    {   // (make_train_plan pads the matrix row pitch to the LDS pitch XP: the 16 rows are one lane-linear piece)
-        float* dst = Xs + 16 * w * XP;
-        if (A.stage_in != nullptr) {
-            const float* src = A.stage_in + (size_t)(first + 16 * w) * p.RP + lane * 4;
-#pragma unroll
-            for (int u = 0; u < NLD; ++u)
-                if (lane + 64 * u < nchunk) LBDRN_LDS_DMA(src + u * 256, dst + u * 256);
-        } else {
-            const int pix_mine = clamp_pix(raw_mine);
-            const float* srcs[NLD];
-            int row = row0, col = col0;
-#pragma unroll
-            for (int u = 0; u < NLD; ++u) {
-                srcs[u] = Ft.rows + (size_t)__shfl(pix_mine, min(row, 15)) * p.RP + 4 * col;
-                row += p.w_dp; col += p.w_df;
-                if (col >= rp4) { col -= rp4; row += 1; }
-            }
-#pragma unroll
-            for (int u = 0; u < NLD; ++u)
-                if (lane + 64 * u < nchunk) LBDRN_LDS_DMA(srcs[u], dst + u * 256);
-        }
-    }
-    // ---- layer-0 fragments -> LDS, this wave's quarter (tile w: G0 blocks of 1 KB, contiguous in the packed copy)
-    {
-        const float* src = Ft.packed + p.pk_w0 + (size_t)w * G0 * 256 + lane * 4;
-        float* dst = R + w * G0 * 256;
-#pragma unroll
-        for (int g = 0; g < G0; ++g) LBDRN_LDS_DMA(src + g * 256, dst + g * 256);
-    }
-#undef LBDRN_LDS_DMA
-    STAMP(1);
-    __syncthreads();   // rows and layer-0 fragments of all four waves are in LDS (drains the LDS-DMA: vmcnt(0))
-    STAMP(2);
-
-    // ---- every other request of the step rides inside layer 0, a few per group of 16 MFMAs, where the vector-memory
-    //      path is otherwise idle (a burst of them stalls the wave: the path takes 64 B/clk per CU): the small matrices
-    //      of the following products (L2 -> VGPR, fragment order), then the transposed ones of the backward products.
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Ft.packed), (short)0,
-                                                                         p.pack_floats * 4, 0x00020000);
-    const int lane16 = lane * 16;
-    auto ldw = [&](int float_base, int block) -> float4 {
-        const v4i32 x = __builtin_amdgcn_raw_buffer_load_b128(wrs, lane16, float_base * 4 + block * 1024, 0);
-        return make_float4(__int_as_float(x[0]), __int_as_float(x[1]), __int_as_float(x[2]), __int_as_float(x[3]));
-    };
-    float4 wh[NL > 1 ? NL - 1 : 1][4][4];    // W_l fragments [out tile][k tile]
-    float4 wl[4];                            // W_last fragments [k tile]
-    float4 wlt[4];                           // W_last^T [hidden tile]
-    float4 wht[NL > 1 ? NL - 1 : 1][4][4];   // W_l^T [in tile][out tile]
-    constexpr int NH = (NL - 1) * 16, NREQ = 2 * NH + 8, PERG = (NREQ + G0 - 1) / G0;
-
-    // ---- layer 0: z^T[64 units][16 samples] = b0 + W0 X^T; lane quarter q walks features q*LQ .. q*LQ+LQ-1.
-    //      Operands of group g+1 (4 fragment blocks + 4 features, LDS) are requested among the 16 MFMAs of group g:
-    //      one wave per SIMD has nobody to hide an instruction burst behind, so reads and requests are dealt out
-    //      between the MFMAs (sched_group_barrier) instead of left where the scheduler would sink them.
-    f32x4 acc[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = bias[0][t];
-    {
-        const float* wbase = W0s + lane * 4;
-        const float* xbase = Xs + srow * XP + q * LQ;
-        float4 aq[2][4], bq[2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) aq[0][t] = *reinterpret_cast<const float4*>(wbase + (t * G0) * 256);
-        bq[0] = *reinterpret_cast<const float4*>(xbase);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int g = 0; g < G0; ++g) {
-            if (g + 1 < G0) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) aq[(g + 1) & 1][t] = *reinterpret_cast<const float4*>(wbase + (t * G0 + g + 1) * 256);
-                bq[(g + 1) & 1] = *reinterpret_cast<const float4*>(xbase + 4 * (g + 1));
-            }
-#pragma unroll
-            for (int j = g * PERG; j < (g + 1) * PERG; ++j) {
-                if (j < NH) wh[j / 16][(j >> 2) & 3][j & 3] = ldw(p.pk_wh, j);
-                else if (j < NH + 4) wl[j - NH] = ldw(p.pk_wl, j - NH);
-                else if (j < NH + 8) wlt[j - NH - 4] = ldw(p.pk_wlt, j - NH - 4);
-                else if (j < 2 * NH + 8) {
-                    const int k = j - NH - 8;   // (l-1)*16 + ti*4 + to
-                    wht[k / 16][(k >> 2) & 3][k & 3] = ldw(p.pk_wht, k);
-                }
-            }
-            const float bx[4] = {bq[g & 1].x, bq[g & 1].y, bq[g & 1].z, bq[g & 1].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float4 x = aq[g & 1][t];
-                    acc[t] = MFMA16(e == 0 ? x.x : e == 1 ? x.y : e == 2 ? x.z : x.w, bx[e], acc[t]);
-                }
-            // the dealt order of this group: MFMA, then a read or a request after every MFMA while there are any
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    STAMP(3);
-    __syncthreads();   // every wave is done with the layer-0 fragments: their space now takes H1.. / dz^T / dz_out
-    STAMP(4);
-
-    float h[4][4];        // the current layer's activations, accumulator layout
-    f32x4 cs[NL][4];      // cos(30 z) of every hidden layer, for the backward pass
-    auto activate = [&](int l) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float sn, co;
-                train_sincos(30.0f * acc[t][r], sn, co);
-                h[t][r] = sn;
-                cs[l][t][r] = co;
-            }
-            *reinterpret_cast<float4*>(Hl(l) + srow * HP + 16 * t + 4 * q) = make_float4(h[t][0], h[t][1], h[t][2], h[t][3]);
-        }
-    };
-    activate(0);
-    STAMP(5);
-
-    // ---- hidden layers: B = the activations where they stand (step (tk, r) multiplies unit 16 tk + 4 q + r)
-#pragma unroll
-    for (int l = 1; l < NL; ++l) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = bias[l][t];
-#pragma unroll
-        for (int tk = 0; tk < 4; ++tk) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int to = 0; to < 4; ++to) {
-                    const float4 x = wh[l - 1][to][tk];
-                    const float a = r == 0 ? x.x : r == 1 ? x.y : r == 2 ? x.z : x.w;
-                    acc[to] = MFMA16(a, h[tk][r], acc[to]);
-                }
-        }
-        activate(l);
-    }
-    STAMP(6);
-
-    // ---- output layer (two accumulators share the 16-step chain) + loss + d(loss)/dz_out
-    float dzo[4];
-    {
-        f32x4 oe = bias_last, oo = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tk = 0; tk < 4; ++tk) {
-            const float4 x = wl[tk];
-            oe = MFMA16(x.x, h[tk][0], oe);
-            oo = MFMA16(x.y, h[tk][1], oo);
-            oe = MFMA16(x.z, h[tk][2], oe);
-            oo = MFMA16(x.w, h[tk][3], oo);
-        }
-        const bool live = srow < nvalid;
-        const float* labrow = Xs + srow * XP + F + 4 * q;   // labels ride behind the features (F need not be a multiple of 4)
-        float lsum = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool ok = live && (4 * q + r) < C;
-            const float y = train_sigmoid(oe[r] + oo[r]);
-            const float d = y - ((4 * q + r) < C ? labrow[r] : 0.0f);
-            lsum += ok ? d * d : 0.0f;                                      // ref LBDRNloss.py:9
-            dzo[r] = ok ? ((2.0f * d) * A.inv) * (y * (1.0f - y)) : 0.0f;    // mse + sigmoid backward
-        }
-        *reinterpret_cast<float4*>(Zo + srow * OP + 4 * q) = make_float4(dzo[0], dzo[1], dzo[2], dzo[3]);
-        lsum = wave_sum(lsum);   // 64 terms in float32 (1e-7 relative), the workgroups' partials are summed in double
-        if (lane == 0) red[w] = lsum;
-        // output-bias gradient of this wave's 16 samples: row sums by DPP, lane 15 of quarter q holds channels 4q..4q+3
-        float bs[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bs[r] = row_sum16(dzo[r]);
-        if (i == 15) *reinterpret_cast<float4*>(red + 4 + 16 * w + 4 * q) = make_float4(bs[0], bs[1], bs[2], bs[3]);
-    }
-    STAMP(7);
-
-    // ---- backward: dh = W^T dz, dz = (dh * cos(30 z)) * 30, layer by layer, still wave-local.  dz is parked
-    //      transposed: unit row, column 16 (s & 3) + (s >> 2) of sample s -- the weight-gradient products then find
-    //      the 16 samples of lane quarter q (samples 4 j + q) in one 64-byte piece
-    const int zcol = 16 * (i & 3) + 4 * w + (i >> 2);
-    float dz[4][4];
-    auto backprop = [&](int l) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dz[t][r] = (acc[t][r] * cs[l][t][r]) * 30.0f;
-                ZT[(size_t)l * TBC * PT + (16 * t + 4 * q + r) * PT + zcol] = dz[t][r];
-            }
-    };
-    {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = zero;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float4 x = wlt[t];
-                const float a = s == 0 ? x.x : s == 1 ? x.y : s == 2 ? x.z : x.w;
-                acc[t] = MFMA16(a, dzo[s], acc[t]);
-            }
-        backprop(NL - 1);
-    }
-#pragma unroll
-    for (int l = NL - 1; l >= 1; --l) {
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = zero;
-#pragma unroll
-        for (int to = 0; to < 4; ++to)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti) {
-                    const float4 x = wht[l - 1][ti][to];
-                    const float a = r == 0 ? x.x : r == 1 ? x.y : r == 2 ? x.z : x.w;
-                    acc[ti] = MFMA16(a, dz[to][r], acc[ti]);
-                }
-        backprop(l - 1);
-    }
-    STAMP(8);
-    __syncthreads();
-    if (tid == 0) Ft.loss_part[wg] = ((double)red[0] + (double)red[1]) + ((double)red[2] + (double)red[3]);
-    STAMP(9);
-
-    // ---- weight gradients: K = the 64 samples (16 steps; lane quarter q, step j = sample 4 j + q).
-    //      dW[unit tile t][input strip nt]: A = dz^T rows of tile t (16 contiguous floats per lane), B = the inputs
-    //      row-major, one float per lane and step.  Wave w takes the strips nt = w, w+4, .. of the first layer against
-    //      all four unit tiles (64 MFMAs on four independent accumulators per 16 reads); the strips left over when
-    //      the strip count is not a multiple of 4 go one tile to each wave; strip w of the hidden layers; tile w of
-    //      the output layer.  Every finished tile leaves as one 1 KB store in the slab's tile order.
-    auto ldrow = [&](const float* row, float (&dst)[16]) {   // 16 contiguous floats of a 16-byte aligned row piece
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 x = *reinterpret_cast<const float4*>(row + 4 * g);
-            dst[4 * g] = x.x; dst[4 * g + 1] = x.y; dst[4 * g + 2] = x.z; dst[4 * g + 3] = x.w;
-        }
-    };
-    auto ldcol = [&](const float* base, int pitch, float (&dst)[16]) {   // column i of 16 rows 4 j + q
-#pragma unroll
-        for (int s = 0; s < 16; ++s) dst[s] = base[(4 * s + q) * pitch + i];
-    };
-    auto put = [&](int off, const f32x4& g, bool early) {
-        if (early) slabw.store(off + lane * 4, g[0], g[1], g[2], g[3]);
-        else slabw.store_plain(off + lane * 4, g[0], g[1], g[2], g[3]);
-    };
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    const int NT0 = p.NT0, NF = NT0 & ~3, rem = NT0 - NF;
-    float az[4][16], b[16], bn[16];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) ldrow(ZT + (16 * t + i) * PT + 16 * q, az[t]);
-    ldcol(Xs + 16 * min(w, NT0 - 1), XP, b);
-    __builtin_amdgcn_sched_barrier(0);
-    auto strip = [&](int nt, int nreads) {   // 64 MFMAs of strip nt (operands in az, b), four 1 KB tile stores; the
-        f32x4 g[4] = {zero4, zero4, zero4, zero4};   // nreads LDS reads requested just before are dealt out between them
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) g[t] = MFMA16(az[t][s], b[s], g[t]);
-        if (nreads <= 16) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 52; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) put((t * NT0 + nt) * 256, g[t], true);
-    };
-    int nt = w;
-    for (; nt + 4 < NF; nt += 4) {   // operands of the strip after this one arrive under its MFMAs
-        ldcol(Xs + 16 * (nt + 4), XP, bn);
-        strip(nt, 16);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) b[s] = bn[s];
-    }
-    // left-over strips of the first layer (tile w of each) and tile w of the output layer: operands requested under
-    // the last full strip.  dW_last[channel slot][hidden 16w..] = sum_s dzo[s][slot] * h_last[s][16w + col]
-    float azw[16], ao[16], bo[16], br[16];
-    ldrow(ZT + (16 * w + i) * PT + 16 * q, azw);
-    ldcol(Zo, OP, ao);
-    ldcol(Hl(NL - 1) + 16 * w, HP, bo);
-    ldcol(Xs + 16 * min(NF, NT0 - 1), XP, br);
-    if (nt < NF) strip(nt, 52);
-    __builtin_amdgcn_sched_barrier(0);
-    STAMP(10);
-    // hidden layers' operands (strip w of H_{l-1}, the four unit tiles of dz_l): requested under the tail's MFMAs
-    float a1[NL > 1 ? NL - 1 : 1][4][16], bh[NL > 1 ? NL - 1 : 1][16];
-#pragma unroll
-    for (int l = 1; l < NL; ++l) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) ldrow(ZT + (size_t)l * TBC * PT + (16 * t + i) * PT + 16 * q, a1[l - 1][t]);
-        ldcol(Hl(l - 1) + 16 * w, HP, bh[l - 1]);
-    }
-    {
-        f32x4 go = zero4, g0 = zero4;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            go = MFMA16(ao[s], bo[s], go);
-            g0 = MFMA16(azw[s], br[s], g0);
-        }
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {   // the hidden layers' 32 operand reads, one after every MFMA of the tail
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        put(p.sl_out + w * 256, go, false);
-        if (rem >= 1) put((w * NT0 + NF) * 256, g0, false);
-    }
-    for (int k = 1; k < rem; ++k) {   // (strip counts 4n+2, 4n+3: rare shapes, one plain chain per extra strip)
-        ldcol(Xs + 16 * (NF + k), XP, br);
-        f32x4 g1 = zero4;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) g1 = MFMA16(azw[s], br[s], g1);
-        put((w * NT0 + NF + k) * 256, g1, false);
-    }
-#pragma unroll
-    for (int l = 1; l < NL; ++l) {
-        f32x4 g[4] = {zero4, zero4, zero4, zero4};
-#pragma unroll
-        for (int s = 0; s < 16; ++s)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) g[t] = MFMA16(a1[l - 1][t][s], bh[l - 1][s], g[t]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) put(p.sl_hid + ((l - 1) * 16 + t * 4 + w) * 256, g[t], false);
-    }
-    STAMP(11);
-    // bias gradients: sums over the 64 samples.  Hidden units: a row of dz^T, two threads per unit (32 columns
-    // each, partner = lane ^ 1, summed low half first); output slots: a column of dz_out on the last wave.
-    if (tid < NL * TBC * 2) {
-        const int u = tid >> 1, half = tid & 1;
-        const float* row = ZT + (size_t)u * PT + 32 * half;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 x = *reinterpret_cast<const float4*>(row + 4 * g);
-            s0 += x.x; s1 += x.y; s2 += x.z; s3 += x.w;
-        }
-        const float mine = (s0 + s1) + (s2 + s3);
-        const float other = __shfl_xor(mine, 1);
-        if (half == 0) slab[p.sl_bias + u] = mine + other;
-    }
-    if (w == 3 && lane < 16)   // output slots: the four waves' partials (loss phase), in wave order
-        slab[p.sl_bias + NL * TBC + lane] = (red[4 + lane] + red[20 + lane]) + (red[36 + lane] + red[52 + lane]);
-    STAMP(12);
-#ifdef LBDRN_TRAIN_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(13);
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp[15])::"memory");
-    if (lane == 0 && A.stamps)
-        for (int k = 0; k < 16; ++k) A.stamps[((size_t)wg * 4 + w) * 16 + k] = stamp[k];
-#endif
 }
 
 // the dynamic-LDS ceiling of a kernel is told to the runtime once per device and kernel (a cache of an idempotent
@@ -1490,28 +1023,6 @@ static int dispatch_nl(const TrainArgs& A, int nwg, hipStream_t s)
     return launch_train<LQ, 3>(A, nwg, s);
 }
 
-template <int LQ, int NL>
-static int launch_wave(const TrainArgs& A, int nwg, hipStream_t s)
-{
-    auto kern = k_train_wave<LQ, NL>;
-    static std::atomic<unsigned long long> configured{0};
-    if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
-    kern<<<nwg, WAVE_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
-    LBDRN_LAUNCH_CHECK();
-    return 0;
-}
-
-static int dispatch_wave(const TrainArgs& A, int nwg, hipStream_t s)
-{
-    const bool one = A.net.nl == 1;
-    switch (A.p.LQ) {
-        case 16: return one ? launch_wave<16, 1>(A, nwg, s) : launch_wave<16, 2>(A, nwg, s);
-        case 32: return one ? launch_wave<32, 1>(A, nwg, s) : launch_wave<32, 2>(A, nwg, s);
-        case 52: return one ? launch_wave<52, 1>(A, nwg, s) : launch_wave<52, 2>(A, nwg, s);
-        default: return one ? launch_wave<64, 1>(A, nwg, s) : launch_wave<64, 2>(A, nwg, s);
-    }
-}
-
 template <int LQ, int NL, int NT0C>
 static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
@@ -1544,7 +1055,6 @@ static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s
 static int dispatch_train(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
     if (A.p.wave == 2) return dispatch_stream(A, nwg, count, s);
-    if (A.p.wave == 1) return dispatch_wave(A, nwg, s);
     switch (A.p.LQ) {
         case 16: return dispatch_nl<16>(A, nwg, s);
         case 32: return dispatch_nl<32>(A, nwg, s);

@@ -1,5 +1,5 @@
 """A/B aid: wall time per tile of codec.fit_many over 6 tiles with 1 and 2 fits in flight, for the train
-kernel named by LBDRN_TRAIN_KERNEL (unset = k_train_mfma, 'lean' = k_train_lean)."""
+kernel named by LBDRN_TRAIN_KERNEL (unset = k_train_stream, 'tile' = k_train_mfma)."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # like bench.py: one hardware queue per fit in flight
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
