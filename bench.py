@@ -41,7 +41,7 @@ def parse():
                    help="timed tiles per GPU (default: 16 on one GPU -- four rounds of the four fits in flight, the first of "
                         "which start in lockstep -- and 8 with --gpus N > 1: at 8 GPUs the 64-tile job of BASELINE.json "
                         "configs[3])")
-    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--warmup", type=int, default=4)
     p.add_argument("--height", type=int, default=2048)
     p.add_argument("--width", type=int, default=2048)
     p.add_argument("--bands", type=int, default=8)
