@@ -121,7 +121,11 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     stream = torch.cuda.current_stream()
     geom, net = fit.geom, fit.net
     N = geom.H * geom.W
-    fwd, step = flops_per_pixel(geom.F, net.bc, net.C, net.nl)
+    fwd, step_ref = flops_per_pixel(geom.F, net.bc, net.C, net.nl)
+    # FLOPs are counted as EXECUTED: the fused step leaves the always-zero window-centre features out of its products
+    # (lbdrn_train_step_features: 192 of 200 at the headline shape); the reference's count rides along
+    Fe = ops.train_step_features(geom, net) if path != ops._lib.PATH_GENERIC else geom.F
+    _, step = flops_per_pixel(Fe, net.bc, net.C, net.nl)
     ws = ops.ApplyWorkspace(geom, net, img_d.device)
     p = fit.best_params
     fast = codec.fast_evaluation()    # the arithmetic the fit's own evaluation passes ran in
@@ -153,7 +157,8 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
                               "minibatch: 128 workgroups of 64 rows, one per CU, on half of the chip's 256 CUs)",
                     "kernel_us": round(t_train * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
                     "unaccounted_us": round((t_epoch / nsteps - t_train - t_reduce) * 1e3, 2),
-                    "flop_per_launch": step * B, "cus_occupied": min(256, (B + 63) // 64),
+                    "flop_per_launch": step * B, "flop_per_launch_reference_arithmetic": step_ref * B,
+                    "features_multiplied": Fe, "cus_occupied": min(256, (B + 63) // 64),
                     "timing": "HIP events on the launch stream over one 512-step epoch of ONE fit, and over the same epoch with "
                               "every training launch doubled / every reduce launch doubled: kernel_us and reduce_adam_us are what one "
                               "more launch of that kernel costs in the dependent sequence (its launch boundary included), "
@@ -452,6 +457,9 @@ def main():
                                    f"{' USE_COORDINATES+EMBEDDING' if a.coords_embedding else ''} "
                                    f"(BASELINE.json configs[1] by default); encode fit + 16-bit weight truncation + decode",
                        "tiles_per_gpu": a.steps, "tiles_in_flight_per_gpu": min(a.in_flight, a.steps),
+                       "tiles_per_launch": int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (
+                           2 if min(a.in_flight, a.steps) >= 4 and path != ops._lib.PATH_GENERIC and
+                           ops.train_group_size(a.bands, a.height, a.width, a.K, a.D, feat_cfg(a), a.bc, a.nl) >= 2 else 1),
                        "warmup_note": "the warm-up tiles run twice on each in-flight stream",
                        "parallelism": f"image-sharded x{world}", "path": a.path},
             "single_tile_ms": round(single_ms, 3),
@@ -465,7 +473,8 @@ def main():
         }
         out["roofline"] = roofline_probe(codec, ops, fit, img_d, a, path)
         # whole job against the matrix peak: algorithmic FLOPs of every timed tile (10 train + 10 evaluation passes + decode)
-        fwd_f, step_f = flops_per_pixel(fit.geom.F, fit.net.bc, fit.net.C, fit.net.nl)
+        fwd_f, _ = flops_per_pixel(fit.geom.F, fit.net.bc, fit.net.C, fit.net.nl)
+        _, step_f = flops_per_pixel(out["roofline"].get("features_multiplied", fit.geom.F), fit.net.bc, fit.net.C, fit.net.nl)
         evals = a.epochs if a.epochs > 1 else 0
         tile_flop = px * (a.epochs * step_f + (evals + 1) * fwd_f)
         out["roofline"]["end_to_end_tflops"] = round(tile_flop * a.steps * world / elapsed / 1e12, 3)

@@ -151,6 +151,15 @@ int lbdrn_train_epoch(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t 
  * run one after another.  The reference has no such call (run.sh:29-42 encodes image after image): results are those
  * of `count` calls of lbdrn_train_epoch, bit for bit. */
 int lbdrn_train_group_max(void);
+/* How many fits of this shape lbdrn_train_epoch_group steps in ONE launch per minibatch: lbdrn_train_group_max() where
+ * the shape runs on the streamed step, 1 where the fits of a group run one after another (the caller then gains nothing
+ * from grouping and should give every fit its own stream).  Only the scalar fields of g are read (tables may be NULL). */
+int32_t lbdrn_train_group_size(const lbdrn_geom *g, const lbdrn_net *net);
+/* Diagnostic (bench.py's FLOP count): the number of input features the fused training step of this shape multiplies.
+ * With RELATIVE and D > 0 the window centre minus itself is an exact 0.0f for every band (LBDRNdataset.py:126-128):
+ * the streamed step leaves those C columns of W_0 out of its products -- they add nothing, their gradient is exactly
+ * 0 and Adam leaves such a weight at its initial value, as in the reference -- and this returns F - C; F otherwise. */
+int32_t lbdrn_train_step_features(const lbdrn_geom *g, const lbdrn_net *net);
 int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom *const *g, const lbdrn_net *net,
                             const uint16_t *const *img, const uint16_t *const *msb, const int64_t *const *perm,
                             int64_t n, int32_t batch_size, float *const *params, float *const *exp_avg,

@@ -497,9 +497,13 @@ __global__ void k_sum_partials_mfma(const double* __restrict__ partial, int n, d
 }
 
 template <int NT, int MODE>
-static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s)
+static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s, bool whole_lds = false)
 {
-    const size_t lds_bytes = (size_t)A.p.lds_floats * 4;
+    // whole_lds (a fit's background evaluation pass): the workgroup asks for 125 of the CU's 128 LDS granules of 1,280
+    // bytes whatever it needs, so that the k_reduce_adam launches of the training chain beside it (4 granules) are
+    // placed on the CUs the chain's own training step has just left, not next to this pass's waves -- there they took
+    // 14.4 instead of 4.9 us (kernel trace of a fit alone, scripts/lone_timeline.py)
+    const size_t lds_bytes = std::max((size_t)A.p.lds_floats * 4, whole_lds ? (size_t)125 * 1280 : (size_t)0);
     auto kern = k_apply_mfma<NT, MODE>;
     // the kernel may use the whole 160 KB of a CU's LDS: told to the runtime once per device and kernel (a cache of an
     // idempotent setting, not state a caller can observe)
@@ -638,12 +642,12 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
                          : launch_apply<4, MODE_DECODE>(A, grid, s);
     } else {
         rc = mode == MODE_EVAL_FAST
-                 ? (A.p.NT == 1 ? launch_apply<1, MODE_EVAL_FAST>(A, grid, s)
-                    : A.p.NT == 2 ? launch_apply<2, MODE_EVAL_FAST>(A, grid, s)
-                                  : launch_apply<4, MODE_EVAL_FAST>(A, grid, s))
-                 : (A.p.NT == 1 ? launch_apply<1, MODE_EVAL>(A, grid, s)
-                    : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s)
-                                  : launch_apply<4, MODE_EVAL>(A, grid, s));
+                 ? (A.p.NT == 1 ? launch_apply<1, MODE_EVAL_FAST>(A, grid, s, background)
+                    : A.p.NT == 2 ? launch_apply<2, MODE_EVAL_FAST>(A, grid, s, background)
+                                  : launch_apply<4, MODE_EVAL_FAST>(A, grid, s, background))
+                 : (A.p.NT == 1 ? launch_apply<1, MODE_EVAL>(A, grid, s, background)
+                    : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s, background)
+                                  : launch_apply<4, MODE_EVAL>(A, grid, s, background));
         if (rc) return rc;
         k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, A.nvirt, sse);
         LBDRN_LAUNCH_CHECK();

@@ -7,6 +7,8 @@
 namespace lbdrn {
 const char* last_error();
 bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net);
+int mfma_train_step_features(const lbdrn_geom& g, const lbdrn_net& net);
+bool mfma_train_takes_groups(const lbdrn_geom& g, const lbdrn_net& net);
 size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
 int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                        const uint16_t* msb, int bs, void* ws, size_t ws_bytes, hipStream_t s);
@@ -242,6 +244,18 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
 }
 
 int lbdrn_train_group_max(void) { return 4; }
+
+int32_t lbdrn_train_group_size(const lbdrn_geom* g, const lbdrn_net* net)
+{
+    if (!g || !net) return 1;
+    return mfma_train_takes_groups(*g, *net) ? lbdrn_train_group_max() : 1;
+}
+
+int32_t lbdrn_train_step_features(const lbdrn_geom* g, const lbdrn_net* net)
+{
+    if (!g || !net) return 0;
+    return mfma_train_step_features(*g, *net);
+}
 
 int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom* const* g, const lbdrn_net* net, const uint16_t* const* img,
                             const uint16_t* const* msb, const int64_t* const* perm, int64_t n, int32_t batch_size,

@@ -38,6 +38,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <utility>
+#include <chrono>
 #include <vector>
 
 #include "common.hpp"
@@ -70,10 +71,36 @@ __host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ ==
 constexpr int TBC_W = 64;
 constexpr int WPT = 68;   // [unit][64 samples] pitch of the transposed dz copies (16-byte rows)
 
+// The features the streamed step multiplies.  With RELATIVE and D > 0 the window's centre minus itself is an exact
+// 0.0f for every band (LBDRNdataset.py:126-128: feature 2P + c (2D+1)^2 + D (2D+1) + D).  Its products add nothing to a
+// pre-activation, the gradient of its weights is a sum of exact zeros, and torch's Adam leaves a parameter whose
+// gradient has always been 0 where it is (exp_avg = exp_avg_sq = 0: the step is 0 / (0 + eps); encode.py:84 sets no
+// weight decay).  So those C columns of W_0 take no part in a fit: the step runs over the Fe = F - C features that
+// can differ from zero (slot j of its order = feature feat_of_slot(j)); F = 200 -> 192 = twelve full MFMA groups instead
+// of thirteen, and the columns keep their initial values in the parameter vector, as they do in the reference.
+struct FeatMap {
+    int Fe;        // features the step multiplies
+    int zP, zs2, zc;   // zs2 > 0: features zP + c zs2 + zc, c = 0, 1, .. are skipped
+};
+__host__ __device__ __forceinline__ int feat_of_slot(int j, const FeatMap& m)
+{
+    if (m.zs2 == 0 || j < m.zP) return j;
+    const int cj = j - m.zP, c = cj / (m.zs2 - 1), r = cj - c * (m.zs2 - 1);
+    return m.zP + c * m.zs2 + r + (r >= m.zc ? 1 : 0);
+}
+__host__ __device__ __forceinline__ int slot_of_feat(int k, const FeatMap& m)   // -1: a skipped feature
+{
+    if (m.zs2 == 0 || k < m.zP) return k;
+    const int ck = k - m.zP, c = ck / m.zs2, r = ck - c * m.zs2;
+    if (r == m.zc) return -1;
+    return m.zP + c * (m.zs2 - 1) + r - (r > m.zc ? 1 : 0);
+}
+
 struct TrainPlan {
-    int LQ;                    // layer-0 quarter length = MFMA steps of layer 0 (F <= 4*LQ)
+    FeatMap fm;
+    int LQ;                    // layer-0 quarter length = MFMA steps of layer 0 (fm.Fe <= 4*LQ)
     int XP;                    // X row pitch = 4*LQ + 4 floats
-    int NT0;                   // 16-wide feature tiles of dW0 = ceil(F/16)
+    int NT0;                   // 16-wide feature tiles of dW0 = ceil(fm.Fe/16)
     int RP;                    // row pitch of the materialised [N][RP] matrix: F features, C labels, pad to x4
     int64_t NP;
     int64_t offW[5], offB[5];  // canonical parameter offsets per layer (index nl = last layer)
@@ -110,18 +137,23 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     TrainPlan p;
     p.RP = (net.F + net.C + 3) / 4 * 4;
     p.LQ = 0;
+    p.fm = FeatMap{net.F, 0, 0, 0};
     int kind = net.nl <= 2 ? train_kernel_choice() : 0;
     if (kind == 2) {   // the streamed step: features in 4 LQ slots, labels in a group of their own
-        for (int lq : {16, 32, 52, 64})
-            if (net.F <= 4 * lq) { p.LQ = lq; break; }
-        if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 0; p.LQ = 0; }
+        static const bool keep_zero = getenv("LBDRN_TRAIN_KEEP_CENTRE") != nullptr;   // A/B measurements
+        const int side = 2 * g.D + 1;
+        if (!keep_zero && g.use_colors && g.relative && g.D > 0 && net.F == 2 * g.P + g.C * side * side)
+            p.fm = FeatMap{net.F - g.C, 2 * g.P, side * side, g.D * side + g.D};
+        for (int lq : {16, 32, 48, 52, 64})
+            if (p.fm.Fe <= 4 * lq) { p.LQ = lq; break; }
+        if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 0; p.LQ = 0; p.fm = FeatMap{net.F, 0, 0, 0}; }
     }
     if (kind != 2)
         for (int lq : {16, 32, 52, 64})
             if (net.F <= 4 * lq && p.RP <= 4 * lq + 4) { p.LQ = lq; break; }
     if (!p.LQ) return false;
     p.XP = 4 * p.LQ + 4;
-    p.NT0 = (net.F + 15) / 16;
+    p.NT0 = (p.fm.Fe + 15) / 16;
     if (kind != 2 && 16 * p.NT0 > p.XP) return false;
     p.NP = param_count(net);
     int64_t o = 0;
@@ -178,6 +210,18 @@ bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net)
     return make_train_plan(g, net, &p) || wide_supported(g, net);
 }
 
+bool mfma_train_takes_groups(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    TrainPlan p;
+    return make_train_plan(g, net, &p) && p.wave == 2;
+}
+
+int mfma_train_step_features(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    TrainPlan p;
+    return make_train_plan(g, net, &p) ? p.fm.Fe : net.F;
+}
+
 struct TrainWsLayout {
     size_t off_rows, off_pack, off_slab, off_loss, off_stage, stage_bytes, off_map, total;
 };
@@ -211,14 +255,15 @@ size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 // what sits at position `pos` of a row of the streamed step's matrix (LQs = its quarter length; 0: rows are
 // features | labels in index order): a row is LQs/4 groups of 16 floats, group g = [quarter kq][e] = feature
 // kq LQs + 4 g + e -- what MFMA group g of layer 0 multiplies -- then one group of 16 label slots.
-// Returns the feature index, F + channel for a label, or -1 (a zero).
-__device__ __forceinline__ int row_source(int pos, int LQs, int F, int C)
+// (slot kq LQs + 4 g + e of the step's feature order, FeatMap.)  Returns the feature index, F + channel for a label, or
+// -1 (a zero).
+__device__ __forceinline__ int row_source(int pos, int LQs, int F, int C, const FeatMap& fm)
 {
     if (LQs == 0) return pos < F + C ? pos : -1;
     const int g = pos >> 4;
     if (g < (LQs >> 2)) {
-        const int f = ((pos >> 2) & 3) * LQs + 4 * g + (pos & 3);
-        return f < F ? f : -1;
+        const int j = ((pos >> 2) & 3) * LQs + 4 * g + (pos & 3);
+        return j < fm.Fe ? feat_of_slot(j, fm) : -1;
     }
     const int ch = pos - 4 * LQs;
     return ch < C ? F + ch : -1;
@@ -228,14 +273,14 @@ __device__ __forceinline__ int row_source(int pos, int LQs, int F, int C)
 // step's order, row_source)
 // (ref LBDRNdataset.py:95-97, 104-131 -- the reference's own [N,F] / [N,C] matrices, side by side)
 __global__ void __launch_bounds__(256)
-    k_build_rows(lbdrn_geom g, int F, int RP, int LQs, const uint16_t* __restrict__ msb,
+    k_build_rows(lbdrn_geom g, int F, int RP, int LQs, FeatMap fm, const uint16_t* __restrict__ msb,
                  const uint16_t* __restrict__ img, float* __restrict__ rows)
 {
     const int64_t HW = (int64_t)g.H * g.W;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= HW * RP) return;
     const int64_t pix = e / RP;
-    const int f = row_source((int)(e - pix * RP), LQs, F, g.C);
+    const int f = row_source((int)(e - pix * RP), LQs, F, g.C, fm);
     const int y = (int)(pix / g.W), x = (int)(pix - (int64_t)y * g.W);
     float v = 0.0f;
     if (f < 0) {
@@ -270,7 +315,7 @@ __global__ void __launch_bounds__(256)
 // index divisions and scattered uint16 gathers: 0.7 TB/s; this one is bound by the 3.5 GB it writes).
 constexpr int BR_TW = 32;
 __global__ void __launch_bounds__(256)
-    k_build_rows_tiled(lbdrn_geom g, int F, int RP, int LQs, const uint16_t* __restrict__ msb,
+    k_build_rows_tiled(lbdrn_geom g, int F, int RP, int LQs, FeatMap fm, const uint16_t* __restrict__ msb,
                        const uint16_t* __restrict__ img, float* __restrict__ rows)
 {
     extern __shared__ float br_lds[];
@@ -310,7 +355,7 @@ __global__ void __launch_bounds__(256)
     int pix = tid / RP, pos = tid - pix * RP;
     const int dp = 256 / RP, df = 256 - dp * RP;
     for (int e = tid; pix < tw; e += 256) {
-        const int f = row_source(pos, LQs, F, g.C);
+        const int f = row_source(pos, LQs, F, g.C, fm);
         float v = 0.0f;
         if (f < 0) {
         } else if (f < g.P) {
@@ -342,7 +387,8 @@ __global__ void __launch_bounds__(256)
 __device__ __forceinline__ int2 frag_pos(int64_t idx, const TrainPlan& p, int F, int nl, int C)
 {
     if (idx < p.offB[0]) {  // W0[n][k]
-        int n = (int)(idx / F), k = (int)(idx - (int64_t)n * F);
+        int n = (int)(idx / F), k = slot_of_feat((int)(idx - (int64_t)n * F), p.fm);
+        if (k < 0) return make_int2(-1, -1);   // a column the step skips (FeatMap)
         int q = k / p.LQ, s = k - q * p.LQ;
         return make_int2(p.pk_w0 + ((((n >> 4) * (p.LQ >> 2) + (s >> 2)) * 64 + q * 16 + (n & 15)) * 4 + (s & 3)), -1);
     }
@@ -387,7 +433,7 @@ __device__ __forceinline__ int64_t slab_to_param(int e, const TrainPlan& p, int 
     if (e < p.sl_hid) {
         int w = tile / p.NT0, nt = tile - w * p.NT0;
         int k = 16 * nt + col;
-        return k < F ? p.offW[0] + (int64_t)(16 * w + row) * F + k : -1;
+        return k < p.fm.Fe ? p.offW[0] + (int64_t)(16 * w + row) * F + feat_of_slot(k, p.fm) : -1;
     }
     if (e < p.sl_out) {
         int t2 = tile - 4 * p.NT0;
@@ -425,13 +471,25 @@ __global__ void __launch_bounds__(256)
 // (torch/optim/adam.py single-tensor path: lerp_, mul_/addcmul_, addcdiv_); refresh the fragment copy.
 // Block = RED_LANES float4 lanes (4*RED_LANES slab elements) x RED_SLICES workgroup slices; the final sum over
 // slices and the update are spread over 4*RED_LANES threads, one slab element each.
+#ifdef LBDRN_TIMELINE
+// plain stores to distinct addresses (no atomics: they would serialise and distort what is measured)
+constexpr int TL_SLOTS = 2048;   // per step: [0] train start (workgroup 0), [1] reduce start (block 0), [2 .. 2+512) train wave ends, [514 ..) reduce block ends
+__device__ __forceinline__ void timeline_store(unsigned long long* tl, int slot, bool drain)
+{
+    if (!tl || slot >= TL_SLOTS) return;
+    unsigned long long t;
+    if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    tl[slot] = t;
+}
+#endif
 struct ReduceFit {
     const float* slabs;
     float *params, *m, *v, *packed;
     const double* loss_part;
     float* loss_out;
 };
-struct ReduceArgs { ReduceFit fit[MAX_GROUP]; };
+struct ReduceArgs { ReduceFit fit[MAX_GROUP]; unsigned long long* tl; };
 
 __global__ void __launch_bounds__(256)
     k_reduce_adam(ReduceArgs R, int nwg, int slab_floats, const int4* __restrict__ map, float step_size, float bc2_sqrt,
@@ -441,6 +499,12 @@ __global__ void __launch_bounds__(256)
     // has exactly this much left, so the reduce launch of one chain runs BESIDE the training step of another instead
     // of waiting for a CU to come free (with four fits in flight the two launches took turns: 13 ms per tile)
     __shared__ __attribute__((aligned(16))) float part[RED_SLICES][4 * RED_LANES];
+    // the chain waits for this launch and it is all latency: where its waves share a SIMD with another kernel's (a
+    // fit's background evaluation pass, other fits' small launches) they go first
+    __builtin_amdgcn_s_setprio(3);
+#ifdef LBDRN_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) timeline_store(R.tl, 1, false);
+#endif
     const ReduceFit& F = R.fit[blockIdx.y];   // the fits of a group: same shape, own state
     const float* __restrict__ slabs = F.slabs;
     float* __restrict__ params = F.params;
@@ -495,6 +559,10 @@ __global__ void __launch_bounds__(256)
         for (int k = 0; k < nwg; ++k) s += F.loss_part[k];
         *F.loss_out = (float)(s / loss_count);
     }
+#ifdef LBDRN_TIMELINE
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.y == 0) timeline_store(R.tl, 514 + blockIdx.x, true);
+#endif
 }
 
 // ------------------------------------------------------------------ the fused step
@@ -521,7 +589,9 @@ struct TrainArgs {
     const int64_t* perm_next;
     int next_n;
     unsigned long long* stamps;  // diagnostic build only (-DLBDRN_TRAIN_STAMPS): [nwg][16] s_memtime
+    unsigned long long* tl;      // diagnostic build only (-DLBDRN_TIMELINE): [steps][4] first start / last end of the step's two launches, 100 MHz
 };
+
 
 #ifdef LBDRN_TRAIN_STAMPS
 #define STAMP(k)                                                                        \
@@ -1043,6 +1113,9 @@ static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s
     switch (A.p.LQ) {
         case 16: return one ? launch_stream<16, 1, 0>(A, nwg, count, s) : launch_stream<16, 2, 0>(A, nwg, count, s);
         case 32: return one ? launch_stream<32, 1, 0>(A, nwg, count, s) : launch_stream<32, 2, 0>(A, nwg, count, s);
+        case 48:
+            if (!one && A.p.NT0 == 12 && !loop_only) return launch_stream<48, 2, 12>(A, nwg, count, s);
+            return one ? launch_stream<48, 1, 0>(A, nwg, count, s) : launch_stream<48, 2, 0>(A, nwg, count, s);
         case 52:
             if (!one && A.p.NT0 == 13 && !loop_only) return launch_stream<52, 2, 13>(A, nwg, count, s);
             return one ? launch_stream<52, 1, 0>(A, nwg, count, s) : launch_stream<52, 2, 0>(A, nwg, count, s);
@@ -1084,6 +1157,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
         const WideWsLayout L = wide_ws_layout(g, net, wp, bs);
         need = L.total; off_rows = L.off_rows;
         p.RP = wp.RP;
+        p.fm = FeatMap{net.F, 0, 0, 0};
     }
     if (!ws || ws_bytes < need) {
         set_error("train workspace too small: %zu < %zu", ws_bytes, need);
@@ -1096,9 +1170,9 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * (size_t)std::max(net.F - 2 * g.P, 0)) * 4;
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
-        k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, msb, img, rows);
+        k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
     } else {
-        k_build_rows<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(g, net.F, p.RP, LQs, msb, img, rows);
+        k_build_rows<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
     }
     LBDRN_LAUNCH_CHECK();
     return 0;
@@ -1158,11 +1232,33 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
     const int max_wg = (bs + TB - 1) / TB;
     LBDRN_HIP_TRY(hipMalloc(&A.stamps, (size_t)max_wg * 8 * 16 * sizeof(unsigned long long)));
 #endif
+    A.tl = nullptr; R.tl = nullptr;
+#ifdef LBDRN_TIMELINE
+    const int tl_steps = (int)((n + bs - 1) / bs);
+    unsigned long long* tl_buf = nullptr;
+    {
+        LBDRN_HIP_TRY(hipMalloc(&tl_buf, (size_t)tl_steps * TL_SLOTS * sizeof(unsigned long long)));
+        LBDRN_HIP_TRY(hipMemset(tl_buf, 0, (size_t)tl_steps * TL_SLOTS * sizeof(unsigned long long)));
+    }
+#endif
     const int rows_per_wg = A.p.wave ? WB : TB;
     const dim3 red_grid((unsigned)(A.p.slab_floats / (4 * RED_LANES)), (unsigned)count);
     int64_t step = step0;
     int si = 0;
+    // diagnostic (LBDRN_HOST_TRACE=1): how long the host spends in each iteration of the launch loop
+    static const bool host_trace = getenv("LBDRN_HOST_TRACE") != nullptr;
+    std::vector<std::pair<int, double>> slow;
+    double host_total = 0.0;
+    auto tprev = std::chrono::steady_clock::now();
+    const auto tbegin = tprev;
     for (int64_t first = 0; first < n; first += bs, ++si) {
+        if (host_trace) {
+            const auto tn = std::chrono::steady_clock::now();
+            const double us = std::chrono::duration<double, std::micro>(tn - tprev).count();
+            host_total += us;
+            if (us > 40.0) slow.emplace_back(si, us);
+            tprev = tn;
+        }
         const int B = (int)std::min<int64_t>(bs, n - first);
         const int nwg = (B + rows_per_wg - 1) / rows_per_wg;
         for (int f = 0; f < MAX_GROUP; ++f) {
@@ -1171,6 +1267,9 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
             R.fit[f].loss_out = (f < count && losses && losses[k]) ? losses[k] + si : nullptr;
         }
         A.batch_n = B;
+#ifdef LBDRN_TIMELINE
+        A.tl = tl_buf + (size_t)TL_SLOTS * si; R.tl = A.tl;
+#endif
         A.inv = 1.0f / ((float)B * (float)net.C);
         const int64_t nextB = std::max<int64_t>(0, std::min<int64_t>(bs, n - first - bs));
         A.stage_in = si > 0 ? stage[si & 1] : nullptr;          // staged by the previous launch
@@ -1191,6 +1290,31 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
             k_reduce_adam<<<red_grid, 256, 0, s>>>(R0, nwg, A.p.slab_floats, map, 0.0f, (float)std::sqrt(bc2), (double)B * net.C);
         }
         LBDRN_LAUNCH_CHECK();
+    }
+#ifdef LBDRN_TIMELINE
+    {
+        LBDRN_HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)tl_steps * TL_SLOTS);
+        LBDRN_HIP_TRY(hipMemcpy(h.data(), tl_buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(tl_buf);
+        double tr = 0, g1 = 0, rd = 0, g2 = 0; int cnt = 0;
+        auto last = [&](int k, int lo, int hi) { unsigned long long m = 0; for (int j = lo; j < hi; ++j) m = std::max(m, h[(size_t)k * TL_SLOTS + j]); return m; };
+        for (int k = 8; k + 1 < tl_steps; ++k) {   // (the first steps of an epoch call start behind its packing launches)
+            const unsigned long long ts = h[(size_t)k * TL_SLOTS], rs = h[(size_t)k * TL_SLOTS + 1], te = last(k, 2, 514), re = last(k, 514, TL_SLOTS);
+            const unsigned long long ts2 = h[(size_t)(k + 1) * TL_SLOTS];
+            tr += (double)(te - ts); g1 += (double)((long long)(rs - te)); rd += (double)(re - rs); g2 += (double)((long long)(ts2 - re));
+            ++cnt;
+        }
+        const double u = 0.01 / std::max(cnt, 1);   // 100 MHz ticks -> us
+        fprintf(stderr, "[lbdrn timeline] per step over %d steps: train first start -> last end %.2f us | -> reduce starts %.2f | reduce %.2f | -> next train starts %.2f | step %.2f us\n",
+                cnt, tr * u, g1 * u, rd * u, g2 * u, (tr + g1 + rd + g2) * u);
+    }
+#endif
+    if (host_trace) {
+        fprintf(stderr, "[lbdrn host trace] %d iterations in %.0f us (%.2f us each); slower than 40 us:", si,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tbegin).count(), host_total / std::max(si, 1));
+        for (auto& e : slow) fprintf(stderr, " %d:%.0f", e.first, e.second);
+        fprintf(stderr, "\n");
     }
 #ifdef LBDRN_TRAIN_STAMPS
     if (A.p.wave) {   // diagnostic: mean cycles per phase over the waves of the last step

@@ -53,6 +53,8 @@ SIGNATURES = {
     "lbdrn_train_epoch": (ctypes.c_int, [_GP, _NP, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64,
                                          _dbl, _vp, _vp, _sz, _i32, _vp]),
     "lbdrn_train_group_max": (ctypes.c_int, []),
+    "lbdrn_train_step_features": (_i32, [_GP, _NP]),
+    "lbdrn_train_group_size": (_i32, [_GP, _NP]),
     "lbdrn_train_epoch_group": (ctypes.c_int, [_i32, _vp, _NP, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _i64, _dbl, _vp,
                                                _vp, _sz, _i32, _vp]),
     "lbdrn_train_profile_mode": (ctypes.c_int, [_i32]),

@@ -325,10 +325,14 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     ~5 us -> train ...), so several independent fits progress together.  How they share the chip is `group`:
     fits of one raster shape are taken `group` at a time and step side by side in ONE launch per minibatch
     (fit_group: 2 x 128 workgroups = every CU, deterministically), and in_flight // group such groups run on their
-    own streams and host threads, one training while the other reduces.  group=None: LBDRN_FIT_GROUP, else 1 (every fit
-    its own chain of 128-workgroup launches: measured on 8 x 2048^2 tiles, ms per tile at group : in flight --
-    1:4 72.8, 2:4 75.5, 2:6 72.3, 3:6 75.6; groups halve the host's launches and tie at six in flight, so the default
-    stays the simple one).  Images are independent fits and
+    own streams and host threads, one training while the other reduces.  group=None: LBDRN_FIT_GROUP, else 2 with four
+    or more in flight, else 1.  What decides it is the number of kernel boundaries on the chip: every launch boundary is
+    an L2 write-back + invalidate across the eight XCDs, and with several chains in flight the boundaries of one chain
+    lengthen those of the others (in-kernel timeline of a step, scripts/stamp_probe_inflight.py on the -DLBDRN_TIMELINE
+    build: 20.8 us alone, 26 with two chains, 34-46 with four) -- pairs halve them.  Measured on 8 x 2048^2 tiles, ms
+    per tile at group : in flight -- 1:4 69.2, 2:4 64.7, 2:6 66.9, 3:6 66.7, 3:9 66.0, 4:8 66.0, 4:4 77.8, 2:2 87.0,
+    1:3 70.1 (before the evaluation pass and the reduce launch were made cheaper, round 3's first measurements, pairs
+    lost: 1:4 72.8, 2:4 75.5).  Images are independent fits and
     every fit seeds the generator itself (`seed`, what each encode.py invocation does, ref encode.py:200-205), so
     results are bit-identical to fitting them one after another, whatever the grouping.
     `then(fit)` runs on the worker's stream right after its fit (weight truncation + reconstruction, payload
@@ -337,7 +341,14 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     if in_flight is None:
         in_flight = 4
     if group is None:
-        group = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or 1
+        group = int(os.environ.get("LBDRN_FIT_GROUP", "0"))
+        if group == 0:
+            group = 1
+            if in_flight >= 4 and images:
+                C, H, W = images[0].shape
+                fcfg = cfg or FeatCfg.from_constants()
+                if ops.train_group_size(C, H, W, K, D, fcfg, base_channel, num_layers) >= 2 and path != ops._lib.PATH_GENERIC:
+                    group = 2
     group = max(1, min(group, in_flight, ops.train_group_max()))
     if draws is not None:
         seed = None

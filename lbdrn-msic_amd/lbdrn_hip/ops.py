@@ -197,6 +197,19 @@ def train_group_max():
     return int(lib().lbdrn_train_group_max())
 
 
+def train_group_size(C, H, W, K, D, cfg, base_channel, num_layers):
+    """How many fits of this shape step in one launch per minibatch (lbdrn_train_group_size; 1: grouping gains nothing)."""
+    g = Geom(C, H, W, K, D, 1, int(cfg.use_colors), int(cfg.relative), int(cfg.P), 0, None, None)
+    net = Net(cfg.feature_dim(C, D), base_channel, C, num_layers)
+    return int(lib().lbdrn_train_group_size(ctypes.byref(g), ctypes.byref(net)))
+
+
+def train_step_features(geom, net):
+    """Input features the fused training step of this shape multiplies (F, or F - C where the window centres are
+    exact zeros and the step leaves them out: lbdrn_train_step_features)."""
+    return int(lib().lbdrn_train_step_features(ctypes.byref(geom.c), ctypes.byref(net)))
+
+
 def train_epoch_group(geoms, net, imgs, msbs, perms, batch_size, params, exp_avgs, exp_avg_sqs, adam_step0, lr,
                       losses=None, path=PATH_AUTO, wss=None):
     """train_epoch for several independent fits of ONE shape, stepping side by side (lbdrn_train_epoch_group: one
