@@ -67,7 +67,7 @@ constexpr int TRAIN_THREADS = 512;  // 8 waves: (neuron tile w = 0..3) x (sample
 constexpr int WB = 64;            // samples per workgroup
 constexpr int WAVE_THREADS = 256;
 constexpr int WOP = 16;           // k_train_wide: [sample][16 channel slots] pitch of dz_out
-__host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ == 32 ? 144 : LQ == 52 ? 208 : 272; }   // k_train_wide: row pitch, matrix = LDS
+__host__ __device__ constexpr int wave_xp(int LQ) { return LQ == 16 ? 80 : LQ == 32 ? 144 : LQ == 48 || LQ == 52 ? 208 : 272; }   // k_train_wide: row pitch, matrix = LDS
 constexpr int TBC_W = 64;
 constexpr int WPT = 68;   // [unit][64 samples] pitch of the transposed dz copies (16-byte rows)
 
@@ -94,6 +94,16 @@ __host__ __device__ __forceinline__ int slot_of_feat(int k, const FeatMap& m)   
     const int ck = k - m.zP, c = ck / m.zs2, r = ck - c * m.zs2;
     if (r == m.zc) return -1;
     return m.zP + c * (m.zs2 - 1) + r - (r > m.zc ? 1 : 0);
+}
+
+// the map of a shape whose fused step skips the window centres (identity otherwise)
+static FeatMap centre_skipping_map(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    static const bool keep_zero = getenv("LBDRN_TRAIN_KEEP_CENTRE") != nullptr;   // A/B measurements
+    const int side = 2 * g.D + 1;
+    if (!keep_zero && g.use_colors && g.relative && g.D > 0 && net.F == 2 * g.P + g.C * side * side)
+        return FeatMap{net.F - g.C, 2 * g.P, side * side, g.D * side + g.D};
+    return FeatMap{net.F, 0, 0, 0};
 }
 
 struct TrainPlan {
@@ -140,10 +150,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     p.fm = FeatMap{net.F, 0, 0, 0};
     int kind = net.nl <= 2 ? train_kernel_choice() : 0;
     if (kind == 2) {   // the streamed step: features in 4 LQ slots, labels in a group of their own
-        static const bool keep_zero = getenv("LBDRN_TRAIN_KEEP_CENTRE") != nullptr;   // A/B measurements
-        const int side = 2 * g.D + 1;
-        if (!keep_zero && g.use_colors && g.relative && g.D > 0 && net.F == 2 * g.P + g.C * side * side)
-            p.fm = FeatMap{net.F - g.C, 2 * g.P, side * side, g.D * side + g.D};
+        p.fm = centre_skipping_map(g, net);
         for (int lq : {16, 32, 48, 52, 64})
             if (p.fm.Fe <= 4 * lq) { p.LQ = lq; break; }
         if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 0; p.LQ = 0; p.fm = FeatMap{net.F, 0, 0, 0}; }
@@ -201,6 +208,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
 }
 
 struct WidePlan;
+static bool make_wide_plan(const lbdrn_geom& g, const lbdrn_net& net, WidePlan* out);
 static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net);
 static size_t wide_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
 
@@ -216,11 +224,6 @@ bool mfma_train_takes_groups(const lbdrn_geom& g, const lbdrn_net& net)
     return make_train_plan(g, net, &p) && p.wave == 2;
 }
 
-int mfma_train_step_features(const lbdrn_geom& g, const lbdrn_net& net)
-{
-    TrainPlan p;
-    return make_train_plan(g, net, &p) ? p.fm.Fe : net.F;
-}
 
 struct TrainWsLayout {
     size_t off_rows, off_pack, off_slab, off_loss, off_stage, stage_bytes, off_map, total;
@@ -253,13 +256,13 @@ size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 // ------------------------------------------------------------------ helper kernels
 
 // what sits at position `pos` of a row of the streamed step's matrix (LQs = its quarter length; 0: rows are
-// features | labels in index order): a row is LQs/4 groups of 16 floats, group g = [quarter kq][e] = feature
+// the step's features (FeatMap) in slot order | labels): a row is LQs/4 groups of 16 floats, group g = [quarter kq][e] = feature
 // kq LQs + 4 g + e -- what MFMA group g of layer 0 multiplies -- then one group of 16 label slots.
 // (slot kq LQs + 4 g + e of the step's feature order, FeatMap.)  Returns the feature index, F + channel for a label, or
 // -1 (a zero).
 __device__ __forceinline__ int row_source(int pos, int LQs, int F, int C, const FeatMap& fm)
 {
-    if (LQs == 0) return pos < F + C ? pos : -1;
+    if (LQs == 0) return pos < fm.Fe ? feat_of_slot(pos, fm) : pos < fm.Fe + C ? F + (pos - fm.Fe) : -1;
     const int g = pos >> 4;
     if (g < (LQs >> 2)) {
         const int j = ((pos >> 2) & 3) * LQs + 4 * g + (pos & 3);
@@ -1059,6 +1062,14 @@ static int stream_lds_total(int LQ, int NL) { return stream_lds(LQ, NL).total; }
 
 #include "train_wide.inc"
 
+int mfma_train_step_features(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    TrainPlan p;
+    if (make_train_plan(g, net, &p)) return p.fm.Fe;
+    WidePlan wp;
+    return make_wide_plan(g, net, &wp) ? wide_plan_features(wp) : net.F;
+}
+
 static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net)
 {
     WidePlan p;
@@ -1157,7 +1168,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
         const WideWsLayout L = wide_ws_layout(g, net, wp, bs);
         need = L.total; off_rows = L.off_rows;
         p.RP = wp.RP;
-        p.fm = FeatMap{net.F, 0, 0, 0};
+        p.fm = wp.fm;
     }
     if (!ws || ws_bytes < need) {
         set_error("train workspace too small: %zu < %zu", ws_bytes, need);
