@@ -38,6 +38,18 @@ def test_geometry_helpers_without_device():
     assert L.lbdrn_feature_dim(ctypes.byref(g)) == 200
     g.P = 25
     assert L.lbdrn_feature_dim(ctypes.byref(g)) == 250
+    # plans of the fused training steps (host arithmetic only): which shapes step in groups, how many features a step
+    # multiplies once the always-zero window centres are left out (LBDRNdataset.py:126-128)
+    g.P = 0
+    rel = lambda bc, nl, F=200: (L.lbdrn_train_step_features(ctypes.byref(g), ctypes.byref(_lib.Net(F, bc, 8, nl))),
+                                 L.lbdrn_train_group_size(ctypes.byref(g), ctypes.byref(_lib.Net(F, bc, 8, nl))))
+    assert rel(64, 2) == (192, L.lbdrn_train_group_max())      # the headline shape: streamed step, groups
+    assert rel(256, 2) == (192, 1)                               # BASELINE configs[2]: the wide step, one fit per launch
+    assert rel(64, 3) == (200, 1)                                # three hidden layers: the tile kernel multiplies all of F
+    g.relative = 0
+    assert rel(64, 2) == (200, L.lbdrn_train_group_max())        # absolute colours: no feature is an exact zero
+    g.relative, g.P = 1, 25
+    assert rel(64, 2, 250) == (242, L.lbdrn_train_group_max())   # configs[4]: 50 positional + 192 colour features
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
