@@ -131,46 +131,79 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     fast = codec.fast_evaluation()    # the arithmetic the fit's own evaluation passes ran in
     ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast)
     t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast), stream, 3)
-    perm = torch.randperm(N, device=img_d.device)
-    pp, m, v = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
-    tws = ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path)
-    run_epoch = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perm, a.bs, pp, m, v, 0, 1e-6, None, path, tws)
-    run_epoch()
     nsteps = (N + a.bs - 1) // a.bs
     peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
     B = min(a.bs, N)
     out = {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "traffic": None}
-    t = {}
-    try:
-        for mode in (0, 2, 1, 0):     # plain, training launch doubled, reduce launch doubled, plain again
-            ops.train_profile_mode(mode)
-            t.setdefault(mode, []).append(event_time_ms(run_epoch, stream, 1))
-    finally:
-        ops.train_profile_mode(0)
-    t_epoch = min(t[0])
-    t_train, t_reduce = (t[2][0] - t_epoch) / nsteps, (t[1][0] - t_epoch) / nsteps
+    # the launch the timed region made: with four or more tiles in flight the fits of one shape step in PAIRS (one launch of
+    # 2 x 128 workgroups per minibatch, one reduce launch for both: codec.fit_many); the probe times that launch, and the
+    # launch of a fit alone beside it
+    per_launch = 1
+    if min(a.in_flight, a.steps) >= 4 and path != ops._lib.PATH_GENERIC:
+        per_launch = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (
+            2 if ops.train_group_size(a.bands, a.height, a.width, a.K, a.D, feat_cfg(a), a.bc, a.nl) >= 2 else 1)
+        per_launch = max(1, min(per_launch, ops.train_group_max()))
+
+    def probe(count):
+        """(step, training launch, reduce launch) in ms for `count` fits per launch: one epoch between an event pair, and
+        the same epoch with every training / every reduce launch doubled (lbdrn_train_profile_mode)"""
+        perms = [torch.randperm(N, device=img_d.device) for _ in range(count)]
+        st = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for _ in range(count)]
+        wss = [ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path) for _ in range(count)]
+        if count == 1:
+            run = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perms[0], a.bs, *st[0], 0, 1e-6, None, path, wss[0])
+        else:
+            run = lambda: ops.train_epoch_group([geom] * count, net, [img_d] * count, [fit.msb] * count, perms, a.bs,
+                                                [x[0] for x in st], [x[1] for x in st], [x[2] for x in st], 0, 1e-6,
+                                                None, path, wss)
+        run()
+        t = {}
+        try:
+            for mode in (0, 2, 1, 0):     # plain, training launch doubled, reduce launch doubled, plain again
+                ops.train_profile_mode(mode)
+                t.setdefault(mode, []).append(event_time_ms(run, stream, 1))
+        finally:
+            ops.train_profile_mode(0)
+        t_epoch = min(t[0])
+        return t_epoch / nsteps, (t[2][0] - t_epoch) / nsteps, (t[1][0] - t_epoch) / nsteps
+
+    t_step, t_train, t_reduce = probe(per_launch)
     fused = t_reduce > 0.5e-3   # a fused MFMA train kernel is in use (the generic path ignores the modes)
     name = "k_train_wide" if net.bc > 64 else "k_train_stream"
+    nwg = (B + 63) // 64
     if fused:
         t_k = t_train
         out.update({"kernel": f"{name} (row gather + forward + loss + backward + weight-gradient slab of one {B}-row "
-                              "minibatch: 128 workgroups of 64 rows, one per CU, on half of the chip's 256 CUs)",
+                              f"minibatch of {per_launch} fit(s): {per_launch} x {nwg} workgroups of 64 rows, one per CU, on "
+                              f"{min(256, per_launch * nwg)} of the chip's 256 CUs)",
+                    "fits_per_launch": per_launch,
                     "kernel_us": round(t_train * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
-                    "unaccounted_us": round((t_epoch / nsteps - t_train - t_reduce) * 1e3, 2),
-                    "flop_per_launch": step * B, "flop_per_launch_reference_arithmetic": step_ref * B,
-                    "features_multiplied": Fe, "cus_occupied": min(256, (B + 63) // 64),
-                    "timing": "HIP events on the launch stream over one 512-step epoch of ONE fit, and over the same epoch with "
-                              "every training launch doubled / every reduce launch doubled: kernel_us and reduce_adam_us are what one "
-                              "more launch of that kernel costs in the dependent sequence (its launch boundary included), "
-                              "train_step_pair_us the whole step, unaccounted_us the rest.  rocprofv3 --kernel-trace averages of the "
-                              "same sequence: profiles/r03_kernel_stats_one_in_flight.csv"})
+                    "unaccounted_us": round((t_step - t_train - t_reduce) * 1e3, 2),
+                    "flop_per_launch": per_launch * step * B, "flop_per_launch_reference_arithmetic": per_launch * step_ref * B,
+                    "features_multiplied": Fe, "cus_occupied": min(256, per_launch * nwg),
+                    "timing": "HIP events on the launch stream over one 512-step epoch of the launch sequence the timed region "
+                              "ran (fits_per_launch fits stepping side by side), and over the same epoch with every training "
+                              "launch doubled / every reduce launch doubled: kernel_us and reduce_adam_us are what one more "
+                              "launch of that kernel costs in the dependent sequence (its launch boundary included), "
+                              "train_step_pair_us the whole step, unaccounted_us the rest.  rocprofv3 --kernel-trace averages: "
+                              "profiles/r03_kernel_stats_pair_alone.csv (this sequence alone on the device), "
+                              "r03_kernel_stats_one_in_flight.csv (one fit per launch), r03_kernel_stats_four_in_flight.csv "
+                              "(the timed region: two such chains in flight, each launch then also waits for CUs)"})
+        if per_launch > 1:   # the launch of a fit alone (what a single tile runs), same method
+            s1, k1, r1 = probe(1)
+            a1 = step * B / (k1 * 1e-3) / 1e12
+            out["single_fit_launch"] = {"kernel_us": round(k1 * 1e3, 2), "reduce_adam_us": round(r1 * 1e3, 2),
+                                        "unaccounted_us": round((s1 - k1 - r1) * 1e3, 2), "train_step_pair_us": round(s1 * 1e3, 2),
+                                        "flop_per_launch": step * B, "cus_occupied": min(256, nwg), "achieved": round(a1, 3),
+                                        "frac": round(a1 / peak, 4),
+                                        "frac_of_occupied_cus": round(a1 / (peak * min(256, nwg) / 256.0), 4)}
     else:  # shape without a fused train kernel: the generic step is many launches
-        t_k = t_epoch / nsteps
+        t_k = t_step
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
-    ach = step * B / (t_k * 1e-3) / 1e12
+    ach = per_launch * step * B / (t_k * 1e-3) / 1e12
     out.update({"achieved": round(ach, 3), "frac": round(ach / peak, 4),
-                "train_step_pair_us": round(t_epoch * 1e3 / nsteps, 2),
-                "train_step_pair_tflops": round(step * N / (t_epoch * 1e-3) / 1e12, 3),
+                "train_step_pair_us": round(t_step * 1e3, 2),
+                "train_step_pair_tflops": round(per_launch * step * B / (t_step * 1e-3) / 1e12, 3),
                 "apply_pass_ms": round(t_eval, 3), "apply_tflops": round(fwd * N / (t_eval * 1e-3) / 1e12, 3),
                 "apply_frac": round(fwd * N / (t_eval * 1e-3) / 1e12 / peak, 4),
                 "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1),
@@ -189,6 +222,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
             tr, ap = c.get("train", {}), c.get("apply_eval", {})
             out["traffic"] = tr.get("hbm_bytes_per_launch")
             out["traffic_algorithmic_bytes"] = B * 16
+            out["traffic_note"] = "counter values are per launch of ONE fit's minibatch (scripts/prof_fit.py runs one fit at a time)"
             out["traffic_kernel"] = tr.get("kernel")
             out["mfma_busy_frac"] = tr.get("mfma_busy_frac_whole_chip")
             out["mfma_busy_frac_occupied_simds"] = tr.get("mfma_busy_frac_occupied_simds")

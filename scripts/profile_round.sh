@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profile pass of a round, run ON the GPU box (gpurun): scripts/profile_round.sh TAG [kt|cfg|pmc|sq ...]
-#   kt   rocprofv3 --kernel-trace --stats of bench.py with one fit in flight and with the default (four)
+#   kt   rocprofv3 --kernel-trace --stats of bench.py with one fit in flight and with the default (four, as two pairs),
+#        and of one pair of fits alone (scripts/prof_pair.py)
 #   cfg  the same for BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING)
 #   pmc  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (--kernel-trace only), per configuration
 #        (bc64, bc256, embed) -> per-kernel mean bytes
@@ -23,7 +24,9 @@ kt)
   rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- python3 bench.py --no-cpu-baseline --in-flight 1 --steps 1 --warmup 0 --repeats 1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
   summarise $OUT/kt1 $OUT/kernel_stats_one_in_flight.csv scripts/rocprof_kernel_stats.py
   rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline --repeats 1 > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
-  summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py ;;
+  summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/ktp -o run -- python3 scripts/prof_pair.py 2048 4 > $OUT/pair_alone.txt 2> $OUT/ktp.err
+  summarise $OUT/ktp $OUT/kernel_stats_pair_alone.csv scripts/rocprof_kernel_stats.py ;;
 cfg)
   rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline -bc 256 --in-flight 2 --steps 2 --repeats 1 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
   summarise $OUT/kt_bc256 $OUT/kernel_stats_bc256.csv scripts/rocprof_kernel_stats.py
