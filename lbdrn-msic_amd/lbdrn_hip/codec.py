@@ -392,13 +392,20 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
             results.append(then(fit) if then is not None else fit)
         return results
     # consecutive images of one shape, `group` at a time
-    jobs, k = [], 0
-    while k < len(images):
-        n = 1
-        while n < group and k + n < len(images) and tuple(images[k + n].shape) == tuple(images[k].shape):
-            n += 1
-        jobs.append((list(range(k, k + n)), list(images[k:k + n]), list(drs_all[k:k + n])))
-        k += n
+    def form(group):
+        jobs, k = [], 0
+        while k < len(images):
+            n = 1
+            while n < group and k + n < len(images) and tuple(images[k + n].shape) == tuple(images[k].shape):
+                n += 1
+            jobs.append((list(range(k, k + n)), list(images[k:k + n]), list(drs_all[k:k + n])))
+            k += n
+        return jobs
+    jobs = form(group)
+    if group > 1 and 2 * sum(len(j[0]) for j in jobs if len(j[0]) > 1) < len(images):
+        # mostly odd ones out (tiles of many shapes): groups would only halve the number of chains
+        group = 1
+        jobs = form(1)
     with ThreadPoolExecutor(max_workers=max(1, in_flight // group)) as pool:
         done_jobs = list(pool.map(work, jobs))
     results = [None] * len(images)
