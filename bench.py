@@ -218,11 +218,12 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     if os.path.exists(pmc) and fused and key and N == 2048 * 2048:
         try:
             d = json.load(open(pmc))
-            c = d.get("configs", {}).get(key, {})
+            c = d.get("configs", {}).get("pair" if key == "bc64" and out.get("fits_per_launch") == 2 else key, {})
             tr, ap = c.get("train", {}), c.get("apply_eval", {})
             out["traffic"] = tr.get("hbm_bytes_per_launch")
-            out["traffic_algorithmic_bytes"] = B * 16
-            out["traffic_note"] = "counter values are per launch of ONE fit's minibatch (scripts/prof_fit.py runs one fit at a time)"
+            out["traffic_algorithmic_bytes"] = B * 16 * (2 if c is d.get("configs", {}).get("pair") else 1)
+            out["traffic_note"] = ("counter values are per launch of a pair of fits (scripts/prof_pair.py)" if out["traffic_algorithmic_bytes"] > B * 16
+                                   else "counter values are per launch of ONE fit's minibatch (scripts/prof_fit.py runs one fit at a time)")
             out["traffic_kernel"] = tr.get("kernel")
             out["mfma_busy_frac"] = tr.get("mfma_busy_frac_whole_chip")
             out["mfma_busy_frac_occupied_simds"] = tr.get("mfma_busy_frac_occupied_simds")

@@ -37,7 +37,9 @@ for f in sorted(os.listdir(src)):
 # (apply_eval: the evaluation pass as a fit runs it -- MODE_EVAL_FAST = 2; the canonical MODE_EVAL = 1 pass where a run used it)
 KERNELS = {"bc64": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
            "bc256": {"train": "k_train_wide", "reduce": "k_reduce_adam", "apply_eval": "k_apply_wide<16, 2, 2>", "apply_decode": "k_apply_wide<16, 2, 0>"},
-           "embed": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"}}
+           "embed": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+           # the launches of a PAIR of bc64 fits stepping side by side (scripts/prof_pair.py): 2 x 128 workgroups, every CU
+           "pair": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>"}}
 out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of scripts/prof_fit.py per "
                  f"configuration (one fit at a time: scripts/profile_round.sh {tag}); per-kernel means in profiles/{tag}_pmc_*.csv and "
                  f"profiles/{tag}_sq_*.csv.  FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half of a wide coalesced read), "
@@ -63,8 +65,8 @@ for cfg, kernels in KERNELS.items():
             e.update(mfma_busy_cycles_per_launch=busy[1], mfma_insts_per_launch=insts[1] if insts else None,
                      duration_us_in_counter_pass=round(busy[2] / 1e3, 2),
                      mfma_busy_frac_whole_chip=round(busy[1] / (1024 * dur_cycles), 4))     # 256 CUs x 4 SIMDs
-            if key == "train":   # 128 workgroups, one compute wave per SIMD: 512 of the chip's 1024 SIMDs
-                e["mfma_busy_frac_occupied_simds"] = round(2 * e["mfma_busy_frac_whole_chip"], 4)
+            if key == "train":   # 128 workgroups (pair: 256), one compute wave per SIMD: 512 (1024) of the chip's 1024 SIMDs
+                e["mfma_busy_frac_occupied_simds"] = round((1 if cfg == "pair" else 2) * e["mfma_busy_frac_whole_chip"], 4)
         if conf:
             e.update(lds_bank_conflict_cycles_per_launch=conf[1], lds_active_cycles_per_launch=ldsact[1] if ldsact else None)
         if coexec:
@@ -76,7 +78,7 @@ for cfg, kernels in KERNELS.items():
         if e:
             cout[key] = e
     if cout:
-        cout["algorithmic_bytes_per_train_launch"] = 8192 * 16
+        cout["algorithmic_bytes_per_train_launch"] = 8192 * 16 * (2 if cfg == "pair" else 1)
         out["configs"][cfg] = cout
 json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

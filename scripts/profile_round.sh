@@ -4,7 +4,7 @@
 #        and of one pair of fits alone (scripts/prof_pair.py)
 #   cfg  the same for BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING)
 #   pmc  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (--kernel-trace only), per configuration
-#        (bc64, bc256, embed) -> per-kernel mean bytes
+#        (bc64, bc256, embed, pair = two fits per launch; CFGS="pair" selects) -> per-kernel mean bytes
 #   sq   two SQ counter passes (8 counters each) per configuration -> per-kernel means
 # Small CSVs land under gpurun_out/prof_TAG/; the databases are deleted as soon as they are summarised.
 # (the program itself follows `--`: the profiler's library has initialised the GPU by then)
@@ -18,7 +18,8 @@ summarise() { # dir out-csv script [filters]
   if [ -n "$DB" ]; then python $3 $DB $2 ${@:4} > ${2%.csv}.txt 2>&1; else echo "no database in $1" > ${2%.csv}.txt; fi
   rm -rf $1
 }
-declare -A PROG=( [bc64]="scripts/prof_fit.py 2048 64 4" [bc256]="scripts/prof_fit.py 2048 256 2" [embed]="scripts/prof_fit.py 2048 64 4 embed" )
+declare -A PROG=( [bc64]="scripts/prof_fit.py 2048 64 4" [bc256]="scripts/prof_fit.py 2048 256 2" [embed]="scripts/prof_fit.py 2048 64 4 embed" [pair]="scripts/prof_pair.py 2048 3" )
+CFGS=${CFGS:-bc64 bc256 embed pair}
 for W in $WHAT; do case $W in
 kt)
   rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- python3 bench.py --no-cpu-baseline --in-flight 1 --steps 1 --warmup 0 --repeats 1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
@@ -33,12 +34,12 @@ cfg)
   rocprofv3 --kernel-trace --stats -d $OUT/kt_embed -o run -- python3 bench.py --no-cpu-baseline --coords-embedding --steps 4 --repeats 1 > $OUT/bench_embed.json 2> $OUT/kt_embed.err
   summarise $OUT/kt_embed $OUT/kernel_stats_embed.csv scripts/rocprof_kernel_stats.py ;;
 pmc)
-  for CFG in bc64 bc256 embed; do for C in FETCH_SIZE WRITE_SIZE; do
+  for CFG in $CFGS; do for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${CFG}_$C -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/pmc_${CFG}_$C.err; echo "pmc $CFG $C rc=$?" >> $OUT/status.txt
     summarise $OUT/pmc_${CFG}_$C $OUT/pmc_${CFG}_$C.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply k_build
   done; done ;;
 sq)
-  for CFG in bc64 bc256 embed; do
+  for CFG in $CFGS; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
       -d $OUT/sq_a_$CFG -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/sq_a_$CFG.err; echo "sq_a $CFG rc=$?" >> $OUT/status.txt
     summarise $OUT/sq_a_$CFG $OUT/sq_a_$CFG.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
