@@ -536,19 +536,33 @@ static size_t wapply_workspace(const lbdrn_geom& g, const lbdrn_net& net)
 }
 
 template <int NT, int NL, int MODE>
-static int launch_wapply(const WApplyArgs& A, int grid, hipStream_t s)
+static int launch_wapply(const WApplyArgs& A, int grid, hipStream_t s, bool whole_lds)
 {
-    k_apply_wide<NT, NL, MODE><<<grid, WA_THREADS, (size_t)A.p.lds_floats * 4, s>>>(A);
+    // whole_lds: a fit's background pass claims its CU's LDS like k_apply_mfma's does (launch_apply), so that the reduce
+    // launches of the training chain beside it land on the CUs the chain's own step has just left
+    const size_t lds_bytes = std::max((size_t)A.p.lds_floats * 4, whole_lds ? (size_t)125 * 1280 : (size_t)0);
+    auto kern = k_apply_wide<NT, NL, MODE>;
+    if (whole_lds) {
+        static std::atomic<unsigned long long> configured{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(configured.load(std::memory_order_relaxed) & bit)) {
+            LBDRN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            configured.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    kern<<<grid, WA_THREADS, lds_bytes, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
 }
 
 template <int MODE>
-static int dispatch_wapply(const WApplyArgs& A, int grid, hipStream_t s)
+static int dispatch_wapply(const WApplyArgs& A, int grid, hipStream_t s, bool whole_lds)
 {
     const bool one = A.net.nl == 1;
-    if (A.p.NT == 8) return one ? launch_wapply<8, 1, MODE>(A, grid, s) : launch_wapply<8, 2, MODE>(A, grid, s);
-    return one ? launch_wapply<16, 1, MODE>(A, grid, s) : launch_wapply<16, 2, MODE>(A, grid, s);
+    if (A.p.NT == 8) return one ? launch_wapply<8, 1, MODE>(A, grid, s, whole_lds) : launch_wapply<8, 2, MODE>(A, grid, s, whole_lds);
+    return one ? launch_wapply<16, 1, MODE>(A, grid, s, whole_lds) : launch_wapply<16, 2, MODE>(A, grid, s, whole_lds);
 }
 
 static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const uint16_t* img,
@@ -581,8 +595,9 @@ static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const
     if (!wstamp_buf) LBDRN_HIP_TRY(hipMalloc(&wstamp_buf, 1024 * 8 * sizeof(unsigned long long)));
     A.stamps = wstamp_buf;
 #endif
-    int rc = mode == MODE_DECODE ? dispatch_wapply<MODE_DECODE>(A, grid, s)
-           : mode == MODE_EVAL_FAST ? dispatch_wapply<MODE_EVAL_FAST>(A, grid, s) : dispatch_wapply<MODE_EVAL>(A, grid, s);
+    const bool claim = background;   // (bc = 256, one tile alone: 569.5 -> 558.5 ms)
+    int rc = mode == MODE_DECODE ? dispatch_wapply<MODE_DECODE>(A, grid, s, false)
+           : mode == MODE_EVAL_FAST ? dispatch_wapply<MODE_EVAL_FAST>(A, grid, s, claim) : dispatch_wapply<MODE_EVAL>(A, grid, s, claim);
     if (rc) return rc;
     if (mode != MODE_DECODE) {
         k_sum_partials_mfma<<<1, 64, 0, s>>>(partial, A.nvirt, sse);
