@@ -309,13 +309,14 @@ __global__ void __launch_bounds__(256)
     rows[e] = v;
 }
 
-// The same matrix, built tile-wise: one block = 32 consecutive pixels of one image row (7.4 KB of LDS at the headline
-// shape: the launch fits beside the training workgroups of other fits, which leave 7.5 KB of a CU's LDS free, and
-// its 3.8 GB of stores ride under their MFMAs instead of holding the chip for 2.8 ms).  The normalised
-// window p = msb/max of the tile (C x (2D+1) rows x (32+2D) columns, reflect-padded) is staged in LDS once --
-// one IEEE division per staged value instead of two per output -- and the outputs leave in row-major order,
-// consecutive threads writing consecutive floats (the per-element kernel above spends its time in 64-bit
-// index divisions and scattered uint16 gathers: 0.7 TB/s; this one is bound by the 3.5 GB it writes).
+// The same matrix, built tile-wise: one block = 32 consecutive pixels of one image row (9.0 KB of LDS at the headline
+// shape: the launch fits beside the training workgroups of other fits, which leave 16.6 KB of a CU's LDS free, and
+// its 3.5 GB of stores ride under their MFMAs instead of holding the chip).  The normalised window p = msb/max of the
+// tile (C x (2D+1) rows x (32+2D) columns, reflect-padded) is staged in LDS once -- one IEEE division per staged value
+// instead of two per output --, what sits at each of the row's positions is tabulated once per block, and the outputs
+// leave in row-major order as 16-byte stores (the per-element kernel above spends its time in 64-bit index divisions
+// and scattered uint16 gathers: 0.7 TB/s; this one: 1.8 ms for the 3.49 GB of a 2048^2 x 8 tile, 2.9 ms before the
+// table and the wide stores).
 constexpr int BR_TW = 32;
 __global__ void __launch_bounds__(256)
     k_build_rows_tiled(lbdrn_geom g, int F, int RP, int LQs, FeatMap fm, const uint16_t* __restrict__ msb,
@@ -348,34 +349,61 @@ __global__ void __launch_bounds__(256)
             cto[k] = (c * side + g.D) * SW + g.D;
         }
     }
-    __syncthreads();
+    // what sits at every position of a row, worked out ONCE per block (row_source and the feature map cost ~40
+    // instructions per element, and there are 872 M elements in a 2048^2 tile: the launch was instruction-bound at
+    // 1.2 TB/s of stores): .x >= 0: colour, tile[.x + pixel] (minus tile[.y + pixel] when .y >= 0); -1: zero; -2: row
+    // table entry .y; -3: column table entry .y; -4: label of channel .y
+    __syncthreads();   // window and offset tables are in LDS
     const bool rel = g.relative && g.D > 0;
+    int2* ptab = reinterpret_cast<int2*>(cto + ncolor + ((ncolor & 1) ? 1 : 0));   // [RP], 8-byte aligned
+    for (int pos = tid; pos < RP; pos += 256) {
+        const int f = row_source(pos, LQs, F, g.C, fm);
+        int2 t = make_int2(-1, 0);
+        if (f < 0) {
+        } else if (f < g.P) t = make_int2(-2, f);
+        else if (f < 2 * g.P) t = make_int2(-3, f - g.P);
+        else if (f < F) t = make_int2(nbo[f - 2 * g.P], rel ? cto[f - 2 * g.P] : -1);
+        else if (f < F + g.C) t = make_int2(-4, f - F);
+        ptab[pos] = t;
+    }
+    __syncthreads();
     const int mask = (1 << g.K) - 1;
     const float maskf = (float)mask;
     float* out = rows + ((int64_t)y * g.W + x0) * RP;
     const int64_t pix0 = (int64_t)y * g.W + x0;
-    // element e' = pix*RP + f of the tile, walked with stride 256 without a division per element
-    int pix = tid / RP, pos = tid - pix * RP;
-    const int dp = 256 / RP, df = 256 - dp * RP;
-    for (int e = tid; pix < tw; e += 256) {
-        const int f = row_source(pos, LQs, F, g.C, fm);
-        float v = 0.0f;
-        if (f < 0) {
-        } else if (f < g.P) {
-            v = g.rowtab[(int64_t)y * g.P + f];
-        } else if (f < 2 * g.P) {
-            v = g.coltab[(int64_t)(x0 + pix) * g.P + (f - g.P)];
-        } else if (f < F) {
-            const int k = f - 2 * g.P;
-            const float nb = tile[nbo[k] + pix];
-            v = rel ? nb - tile[cto[k] + pix] : nb;
-        } else if (f < F + g.C) {
-            v = (float)((int)img[(int64_t)(f - F) * HW + pix0 + pix] & mask) / maskf;
+    auto value = [&](int pos, int pix) -> float {
+        const int2 t = ptab[pos];
+        if (t.x >= 0) {
+            const float nb = tile[t.x + pix];
+            return t.y >= 0 ? nb - tile[t.y + pix] : nb;
         }
-        out[e] = v;
-        pix += dp;
-        pos += df;
-        if (pos >= RP) { pos -= RP; pix += 1; }
+        if (t.x == -1) return 0.0f;
+        if (t.x == -2) return g.rowtab[(int64_t)y * g.P + t.y];
+        if (t.x == -3) return g.coltab[(int64_t)(x0 + pix) * g.P + t.y];
+        return (float)((int)img[(int64_t)t.y * HW + pix0 + pix] & mask) / maskf;
+    };
+    if ((RP & 3) == 0) {
+        // four consecutive positions of one pixel per thread and trip: one 16-byte store (rows are 16-byte aligned: RP % 4 == 0)
+        const int RQ = RP >> 2;
+        int pix = tid / RQ, pq = tid - pix * RQ;
+        const int dp = 256 / RQ, dq = 256 - dp * RQ;
+        while (pix < tw) {
+            const int pos = 4 * pq;
+            const float4 v = make_float4(value(pos, pix), value(pos + 1, pix), value(pos + 2, pix), value(pos + 3, pix));
+            *reinterpret_cast<float4*>(out + (int64_t)pix * RP + pos) = v;
+            pix += dp;
+            pq += dq;
+            if (pq >= RQ) { pq -= RQ; pix += 1; }
+        }
+    } else {
+        int pix = tid / RP, pos = tid - pix * RP;
+        const int dp = 256 / RP, df = 256 - dp * RP;
+        for (int e = tid; pix < tw; e += 256) {
+            out[e] = value(pos, pix);
+            pix += dp;
+            pos += df;
+            if (pos >= RP) { pos -= RP; pix += 1; }
+        }
     }
 }
 
@@ -1178,7 +1206,8 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     const int64_t total = (int64_t)g.H * g.W * p.RP;
     LBDRN_REQUIRE((total + 255) / 256 < ((int64_t)1 << 31), "image too large for one launch");
     const int side = 2 * g.D + 1;
-    const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * (size_t)std::max(net.F - 2 * g.P, 0)) * 4;
+    const size_t ncol = (size_t)std::max(net.F - 2 * g.P, 0);
+    const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + (ncol & 1) + 2 * (size_t)p.RP) * 4;   // window + offsets + position table
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
         k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
