@@ -59,6 +59,9 @@ def parse():
                    help="tiles progressing at a time on each GPU (independent fits on their own streams)")
     p.add_argument("--repeats", type=int, default=3, help="repeats of the timed region; the median is reported")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-other-configs", action="store_true",
+                   help="skip the short legs of BASELINE.json configs[2] (bc = 256) and configs[4] (coordinates + embedding) "
+                        "that a default one-GPU run of the headline configuration appends as `other_configs`")
     p.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline crop")
     p.add_argument("--cpu-epochs", type=int, default=1,
                    help="epochs of the recipe the CPU baseline runs on its crop (scaled to the full recipe)")
@@ -81,6 +84,16 @@ def run_images(codec, ops, tiles, a, path):
         return fit, codec.apply_device(fit.geom, fit.net, fit.msb, params, path=path)
     return codec.fit_many(tiles, a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=feat_cfg(a), path=path,
                           seed=SEED, in_flight=a.in_flight, then=finish)
+
+
+def tiles_per_launch(a, ops, path):
+    """How many fits one training launch of the timed region carries (codec.fit_many: pairs with four or more of one
+    shape in flight on the streamed bc = 64 step)."""
+    if min(a.in_flight, a.steps) < 4 or path == ops._lib.PATH_GENERIC:
+        return 1
+    n = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (
+        2 if ops.train_group_size(a.bands, a.height, a.width, a.K, a.D, feat_cfg(a), a.bc, a.nl) >= 2 else 1)
+    return max(1, min(n, ops.train_group_max()))
 
 
 def flops_per_pixel(F, bc, C, nl):
@@ -109,15 +122,34 @@ def config_key(a):
     return None
 
 
-def roofline_probe(codec, ops, fit, img_d, a, path):
+def committed_profile(key, fits_per_launch):
+    """What profiles/pmc_summary.json (scripts/make_pmc_summary.py, committed) holds for this configuration: the counter
+    pass, the rocprofv3 --kernel-trace average of the training launch, the in-kernel timeline and stamp summaries."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if not (os.path.exists(pmc) and key):
+        return {}, {}
+    try:
+        d = json.load(open(pmc))
+    except Exception:
+        return {}, {}
+    ckey = "pair" if key == "bc64" and fits_per_launch == 2 else key
+    return d.get("configs", {}).get(ckey, {}), d
+
+
+def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single=True):
     """Live HIP-event timing, on the launch stream, right after the timed region (same process, same tile).
-    Dominant kernel = the fused training step (5120 launches per tile, ~55 % of the GPU time of a fit).  ONE source for
-    both kernels of a step: a real 512-step epoch (train, reduce/Adam, train, ...) between one event pair, then the same
-    epoch with every training launch doubled and with every reduce launch doubled (lbdrn_train_profile_mode): the
-    differences are what one more launch of either kernel costs inside the dependent sequence, launch boundary included;
-    what the pair costs beyond the two is reported as `unaccounted_us`.  The fused apply kernel is reported beside it.
-    Counter-derived fields (traffic, mfma_busy_frac) come from the committed rocprofv3 --pmc summary of the same
-    kernels at this configuration (profiles/pmc_summary.json, keyed by configuration and kernel)."""
+    Dominant kernel = the fused training step (5120 launches per tile, ~55 % of the GPU time of a fit).
+
+    `kernel_us` -- the figure `achieved` and `frac` are computed from -- is the training kernel's OWN average duration:
+    one 512-launch epoch of training launches back to back between one event pair (lbdrn_train_profile_mode 3: the
+    reduce/Adam launches left out, every launch on its own slice of the permutation = cold rows, its launch boundary
+    included).  Beside it, from the same probe: the whole step (train, reduce/Adam, train, ...: `train_step_pair_us`) and
+    what one MORE launch of either kernel costs inside that dependent sequence (`marginal_us`, `reduce_adam_us`: the
+    epoch with every training / reduce launch doubled -- the doubled launch finds its rows warm, so this is a lower
+    bound of the kernel, reported for the step's accounting only).  The committed rocprofv3 --kernel-trace average of the
+    same launch sequence (profiles/, via pmc_summary.json) rides along as `rocprof_kernel_us`, and `frac` is the SMALLER
+    of the two fractions, so that it never exceeds what the committed trace gives.  Counter-derived fields (traffic,
+    mfma_busy_frac) come from the committed rocprofv3 --pmc summary of the same kernels at this configuration."""
     stream = torch.cuda.current_stream()
     geom, net = fit.geom, fit.net
     N = geom.H * geom.W
@@ -138,15 +170,12 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
     # the launch the timed region made: with four or more tiles in flight the fits of one shape step in PAIRS (one launch of
     # 2 x 128 workgroups per minibatch, one reduce launch for both: codec.fit_many); the probe times that launch, and the
     # launch of a fit alone beside it
-    per_launch = 1
-    if min(a.in_flight, a.steps) >= 4 and path != ops._lib.PATH_GENERIC:
-        per_launch = int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (
-            2 if ops.train_group_size(a.bands, a.height, a.width, a.K, a.D, feat_cfg(a), a.bc, a.nl) >= 2 else 1)
-        per_launch = max(1, min(per_launch, ops.train_group_max()))
+    if per_launch is None:
+        per_launch = tiles_per_launch(a, ops, path)
 
     def probe(count):
-        """(step, training launch, reduce launch) in ms for `count` fits per launch: one epoch between an event pair, and
-        the same epoch with every training / every reduce launch doubled (lbdrn_train_profile_mode)"""
+        """per step, in ms, for `count` fits per launch: (whole step, training launch alone = mode 3, one more training
+        launch = mode 2 - mode 0, one more reduce launch = mode 1 - mode 0)"""
         perms = [torch.randperm(N, device=img_d.device) for _ in range(count)]
         st = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for _ in range(count)]
         wss = [ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path) for _ in range(count)]
@@ -159,40 +188,46 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
         run()
         t = {}
         try:
-            for mode in (0, 2, 1, 0):     # plain, training launch doubled, reduce launch doubled, plain again
+            for mode in (0, 3, 2, 1, 3, 0):     # plain, training launches alone, training doubled, reduce doubled, again
                 ops.train_profile_mode(mode)
                 t.setdefault(mode, []).append(event_time_ms(run, stream, 1))
         finally:
             ops.train_profile_mode(0)
         t_epoch = min(t[0])
-        return t_epoch / nsteps, (t[2][0] - t_epoch) / nsteps, (t[1][0] - t_epoch) / nsteps
+        return t_epoch / nsteps, min(t[3]) / nsteps, (t[2][0] - t_epoch) / nsteps, (t[1][0] - t_epoch) / nsteps
 
-    t_step, t_train, t_reduce = probe(per_launch)
+    t_step, t_own, t_train, t_reduce = probe(per_launch)
     fused = t_reduce > 0.5e-3   # a fused MFMA train kernel is in use (the generic path ignores the modes)
     name = "k_train_wide" if net.bc > 64 else "k_train_stream"
     nwg = (B + 63) // 64
+    key = config_key(a)
+    prof, whole = committed_profile(key if N == 2048 * 2048 else None, per_launch)
     if fused:
-        t_k = t_train
-        out.update({"kernel": f"{name} (row gather + forward + loss + backward + weight-gradient slab of one {B}-row "
+        t_k = t_own
+        out.update({"kernel": f"{name} (row gather + forward + loss + backward + weight gradients of one {B}-row "
                               f"minibatch of {per_launch} fit(s): {per_launch} x {nwg} workgroups of 64 rows, one per CU, on "
                               f"{min(256, per_launch * nwg)} of the chip's 256 CUs)",
                     "fits_per_launch": per_launch,
-                    "kernel_us": round(t_train * 1e3, 2), "reduce_adam_us": round(t_reduce * 1e3, 2),
+                    "kernel_us": round(t_own * 1e3, 2), "marginal_us": round(t_train * 1e3, 2),
+                    "reduce_adam_us": round(t_reduce * 1e3, 2),
                     "unaccounted_us": round((t_step - t_train - t_reduce) * 1e3, 2),
                     "flop_per_launch": per_launch * step * B, "flop_per_launch_reference_arithmetic": per_launch * step_ref * B,
                     "features_multiplied": Fe, "cus_occupied": min(256, per_launch * nwg),
-                    "timing": "HIP events on the launch stream over one 512-step epoch of the launch sequence the timed region "
-                              "ran (fits_per_launch fits stepping side by side), and over the same epoch with every training "
-                              "launch doubled / every reduce launch doubled: kernel_us and reduce_adam_us are what one more "
-                              "launch of that kernel costs in the dependent sequence (its launch boundary included), "
-                              "train_step_pair_us the whole step, unaccounted_us the rest.  rocprofv3 --kernel-trace averages: "
-                              "profiles/r03_kernel_stats_pair_alone.csv (this sequence alone on the device), "
-                              "r03_kernel_stats_one_in_flight.csv (one fit per launch), r03_kernel_stats_four_in_flight.csv "
-                              "(the timed region: two such chains in flight, each launch then also waits for CUs)"})
-        if per_launch > 1:   # the launch of a fit alone (what a single tile runs), same method
-            s1, k1, r1 = probe(1)
-            a1 = step * B / (k1 * 1e-3) / 1e12
-            out["single_fit_launch"] = {"kernel_us": round(k1 * 1e3, 2), "reduce_adam_us": round(r1 * 1e3, 2),
+                    "timing": "HIP events on the launch stream.  kernel_us: one 512-launch epoch of the training launch the "
+                              "timed region made (fits_per_launch fits side by side), back to back without the reduce/Adam "
+                              "launches, every launch on its own rows (lbdrn_train_profile_mode 3) -- the kernel's own average "
+                              "duration, launch boundary included; achieved = flop_per_launch / kernel_us.  "
+                              "train_step_pair_us: the real epoch (train, reduce/Adam, train, ...) per step; marginal_us / "
+                              "reduce_adam_us: what one more launch of either kernel costs in that sequence (epoch with the "
+                              "launch doubled; the doubled training launch finds its rows warm: a lower bound, not the "
+                              "kernel); unaccounted_us the rest of the step.  rocprof_kernel_us: the committed rocprofv3 "
+                              "--kernel-trace average of the same launch sequence (profiles/, see rocprof_source); frac = "
+                              "min(frac_live, frac_rocprof)"})
+        if with_single and per_launch > 1:   # the launch of a fit alone (what a single tile runs), same method
+            s1, o1, k1, r1 = probe(1)
+            a1 = step * B / (o1 * 1e-3) / 1e12
+            out["single_fit_launch"] = {"kernel_us": round(o1 * 1e3, 2), "marginal_us": round(k1 * 1e3, 2),
+                                        "reduce_adam_us": round(r1 * 1e3, 2),
                                         "unaccounted_us": round((s1 - k1 - r1) * 1e3, 2), "train_step_pair_us": round(s1 * 1e3, 2),
                                         "flop_per_launch": step * B, "cus_occupied": min(256, nwg), "achieved": round(a1, 3),
                                         "frac": round(a1 / peak, 4),
@@ -201,7 +236,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
         t_k = t_step
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
     ach = per_launch * step * B / (t_k * 1e-3) / 1e12
-    out.update({"achieved": round(ach, 3), "frac": round(ach / peak, 4),
+    out.update({"achieved": round(ach, 3), "frac": round(ach / peak, 4), "frac_live": round(ach / peak, 4),
                 "train_step_pair_us": round(t_step * 1e3, 2),
                 "train_step_pair_tflops": round(per_launch * step * B / (t_step * 1e-3) / 1e12, 3),
                 "apply_pass_ms": round(t_eval, 3), "apply_tflops": round(fwd * N / (t_eval * 1e-3) / 1e12, 3),
@@ -213,25 +248,29 @@ def roofline_probe(codec, ops, fit, img_d, a, path):
         # the kernel holds half of the chip (two fits' steps run side by side): the same rate against the peak of
         # the CUs it occupies
         out["frac_of_occupied_cus"] = round(ach / (peak * out["cus_occupied"] / 256.0), 4)
-    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")   # committed rocprofv3 --pmc summary, if any
-    key = config_key(a)
-    if os.path.exists(pmc) and fused and key and N == 2048 * 2048:
-        try:
-            d = json.load(open(pmc))
-            c = d.get("configs", {}).get("pair" if key == "bc64" and out.get("fits_per_launch") == 2 else key, {})
-            tr, ap = c.get("train", {}), c.get("apply_eval", {})
-            out["traffic"] = tr.get("hbm_bytes_per_launch")
-            out["traffic_algorithmic_bytes"] = B * 16 * (2 if c is d.get("configs", {}).get("pair") else 1)
-            out["traffic_note"] = ("counter values are per launch of a pair of fits (scripts/prof_pair.py)" if out["traffic_algorithmic_bytes"] > B * 16
-                                   else "counter values are per launch of ONE fit's minibatch (scripts/prof_fit.py runs one fit at a time)")
-            out["traffic_kernel"] = tr.get("kernel")
-            out["mfma_busy_frac"] = tr.get("mfma_busy_frac_whole_chip")
-            out["mfma_busy_frac_occupied_simds"] = tr.get("mfma_busy_frac_occupied_simds")
-            out["lds_bank_conflict_cycles_per_launch"] = tr.get("lds_bank_conflict_cycles_per_launch")
-            out["apply_mfma_busy_frac"] = ap.get("mfma_busy_frac_whole_chip")
-            out["counters_source"] = d.get("source")
-        except Exception:
-            pass
+    if prof and fused:
+        tr, ap = prof.get("train", {}), prof.get("apply_eval", {})
+        pair = per_launch == 2 and key == "bc64"
+        out["traffic"] = tr.get("hbm_bytes_per_launch")
+        out["traffic_algorithmic_bytes"] = B * 16 * (2 if pair else 1)
+        out["traffic_note"] = ("counter values are per launch of a pair of fits (scripts/prof_pair.py)" if pair
+                               else "counter values are per launch of ONE fit's minibatch (scripts/prof_fit.py runs one fit at a time)")
+        out["traffic_kernel"] = tr.get("kernel")
+        out["mfma_busy_frac"] = tr.get("mfma_busy_frac_whole_chip")
+        out["mfma_busy_frac_occupied_simds"] = tr.get("mfma_busy_frac_occupied_simds")
+        out["lds_bank_conflict_cycles_per_launch"] = tr.get("lds_bank_conflict_cycles_per_launch")
+        out["apply_mfma_busy_frac"] = ap.get("mfma_busy_frac_whole_chip")
+        out["counters_source"] = whole.get("source")
+        kt = prof.get("kernel_trace", {})      # the committed rocprofv3 --kernel-trace --stats average of this launch
+        if kt.get("train_avg_us"):
+            r_us = float(kt["train_avg_us"])
+            r_ach = per_launch * step * B / (r_us * 1e-6) / 1e12
+            out.update({"rocprof_kernel_us": r_us, "rocprof_kernel_min_us": kt.get("train_min_us"),
+                        "rocprof_source": kt.get("source"), "frac_rocprof": round(r_ach / peak, 4),
+                        "frac": round(min(ach, r_ach) / peak, 4)})
+        for extra in ("timeline", "stamps"):   # in-kernel evidence (s_memrealtime builds), committed as data
+            if prof.get(extra):
+                out[extra] = prof[extra]
     return out
 
 
@@ -290,6 +329,83 @@ def cpu_baseline(a):
                       f"{fb[2]:.1f}s; form A (the value) = DataLoader(num_workers={workers}) + per-step Adam + "
                       f"concatenating eval metric at {best_th} threads: measured {form_a[3]:.1f}s -> encode {form_a[1]:.1f}s "
                       f"decode {form_a[2]:.1f}s"}
+
+
+def tile_flops(a, ops, fit, path):
+    """Algorithmic FLOPs of one tile as executed: `epochs` training passes (the fused step's feature count), as many
+    evaluation passes (none for a one-epoch fit) and the decode pass over all F features."""
+    Fe = ops.train_step_features(fit.geom, fit.net) if path != ops._lib.PATH_GENERIC else fit.geom.F
+    fwd_f, _ = flops_per_pixel(fit.geom.F, fit.net.bc, fit.net.C, fit.net.nl)
+    _, step_f = flops_per_pixel(Fe, fit.net.bc, fit.net.C, fit.net.nl)
+    evals = a.epochs if a.epochs > 1 else 0
+    return a.height * a.width * (a.epochs * step_f + (evals + 1) * fwd_f)
+
+
+def lone_tile(codec, ops, tile, a, path, laps_n=3):
+    """One tile alone on the device (nothing else in flight): encode fit | truncation + decode, median of `laps_n`."""
+    one = argparse.Namespace(**vars(a))
+    one.in_flight = 1
+    run_images(codec, ops, [tile], one, path)      # untimed: this stream's allocator pool has not held a workspace yet
+    torch.cuda.synchronize()
+    laps = []
+    for _ in range(laps_n):
+        ts = time.perf_counter()
+        lone = codec.fit_many([tile], a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=feat_cfg(a), path=path,
+                              seed=SEED, in_flight=1)[0]
+        torch.cuda.synchronize()
+        tm = time.perf_counter()
+        rec = codec.apply_device(lone.geom, lone.net, lone.msb, codec.truncate_device(lone.best_params, 16), path=path)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        laps.append(((te - ts) * 1e3, (tm - ts) * 1e3, (te - tm) * 1e3))
+    laps.sort()
+    ms, enc, dec = laps[len(laps) // 2]
+    return {"ms": ms, "encode_ms": enc, "decode_ms": dec, "fit": lone, "rec": rec}
+
+
+def side_leg(codec, ops, tiles, a, path, label, **over):
+    """A short leg of another BASELINE.json configuration inside the same call: warm-up tiles twice per in-flight stream,
+    ONE timed region of `steps` tiles with `in_flight` progressing together, one tile alone (median of 3), the training
+    launch's own duration (roofline_probe without the single-fit detour).  Same tiles, same method, same clock as the
+    headline; one repeat instead of three."""
+    b = argparse.Namespace(**vars(a))
+    for k, v in over.items():
+        setattr(b, k, v)
+    t_leg = time.perf_counter()
+    take = [tiles[k % len(tiles)] for k in range(b.warmup + b.steps)]     # (inputs are read-only: a tile may serve twice)
+    for _ in range(2):
+        run_images(codec, ops, take[:b.warmup], b, path)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done = run_images(codec, ops, take[b.warmup:], b, path)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fit, rec = done[-1]
+    img_d = take[-1]
+    diff = (img_d.view(torch.int16).to(torch.int32) & 0xFFFF).float() - (rec.to(torch.int32) & 0xFFFF).float()
+    mse = float((diff * diff).mean().item())
+    single = lone_tile(codec, ops, img_d, b, path)
+    same = bool(torch.equal(single["fit"].best_params.view(torch.int32), fit.best_params.view(torch.int32))
+                and torch.equal(single["rec"], rec))
+    px = b.height * b.width
+    tile_flop = tile_flops(b, ops, fit, path)
+    roof = roofline_probe(codec, ops, fit, img_d, b, path, with_single=False)
+    keep = ("kernel", "fits_per_launch", "kernel_us", "marginal_us", "reduce_adam_us", "unaccounted_us", "train_step_pair_us",
+            "flop_per_launch", "achieved", "frac", "frac_live", "frac_rocprof", "rocprof_kernel_us", "rocprof_source",
+            "frac_of_occupied_cus", "apply_pass_ms", "apply_frac", "traffic", "mfma_busy_frac", "mfma_busy_frac_occupied_simds")
+    out = {"workload": label, "steps": b.steps, "warmup": b.warmup, "tiles_in_flight": min(b.in_flight, b.steps),
+           "tiles_per_launch": tiles_per_launch(b, ops, path), "repeats": 1,
+           "ms_per_step": round(elapsed / b.steps * 1e3, 3), "mpixels_per_s": round(px * b.steps / elapsed / 1e6, 4),
+           "single_tile_ms": round(single["ms"], 3), "single_tile_encode_ms": round(single["encode_ms"], 3),
+           "single_tile_decode_ms": round(single["decode_ms"], 3),
+           "end_to_end_frac": round(tile_flop * b.steps / elapsed / 1e12 / 157.3, 4),
+           "single_tile_end_to_end_frac": round(tile_flop / (single["ms"] * 1e-3) / 1e12 / 157.3, 4),
+           "timed_equals_lone": same, "recon_mse_last_tile": round(mse, 4),
+           "roofline": {k: roof[k] for k in keep if k in roof}}
+    del single, done, fit, rec
+    torch.cuda.empty_cache()      # the next leg's workspaces have other sizes
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    return out
 
 
 def launch_ranks(a):
@@ -455,25 +571,14 @@ def main():
     img_d, mse = tiles[-1], recs[-1][1]
 
     # one tile alone on the GPU (BASELINE.json configs[1] is "a single tile"): rank 0, after the clock
-    single_ms = None
+    single = None
     if rank == 0:
-        one = argparse.Namespace(**vars(a))
-        one.in_flight = 1
-        run_images(codec, ops, tiles[-1:], one, path)      # untimed: this stream's allocator pool has not held a workspace yet
-        torch.cuda.synchronize()
-        laps = []
-        for _ in range(3):                                   # median of three, encode and decode apart
-            ts = time.perf_counter()
-            lone = codec.fit_many(tiles[-1:], a.K, a.D, a.bc, a.nl, a.lr, a.bs, a.epochs, cfg=feat_cfg(a), path=path,
-                                  seed=SEED, in_flight=1)[0]
-            torch.cuda.synchronize()
-            tm = time.perf_counter()
-            codec.apply_device(lone.geom, lone.net, lone.msb, codec.truncate_device(lone.best_params, 16), path=path)
-            torch.cuda.synchronize()
-            te = time.perf_counter()
-            laps.append(((te - ts) * 1e3, (tm - ts) * 1e3, (te - tm) * 1e3))
-        laps.sort()
-        single_ms, single_enc_ms, single_dec_ms = laps[1]
+        single = lone_tile(codec, ops, tiles[-1], a, path)
+        # the launch sequence the timed region runs (pairs of fits per launch, four host threads) against the same fit
+        # alone: bit-identical weights and raster, or the line says so
+        lone, lone_rec = single["fit"], single["rec"]
+        timed_equals_lone = bool(torch.equal(lone.best_params.view(torch.int32), fit.best_params.view(torch.int32))
+                                 and torch.equal(lone_rec, rec))
 
     if rank == 0:
         px = a.height * a.width
@@ -492,28 +597,38 @@ def main():
                                    f"{' USE_COORDINATES+EMBEDDING' if a.coords_embedding else ''} "
                                    f"(BASELINE.json configs[1] by default); encode fit + 16-bit weight truncation + decode",
                        "tiles_per_gpu": a.steps, "tiles_in_flight_per_gpu": min(a.in_flight, a.steps),
-                       "tiles_per_launch": int(os.environ.get("LBDRN_FIT_GROUP", "0")) or (
-                           2 if min(a.in_flight, a.steps) >= 4 and path != ops._lib.PATH_GENERIC and
-                           ops.train_group_size(a.bands, a.height, a.width, a.K, a.D, feat_cfg(a), a.bc, a.nl) >= 2 else 1),
+                       "tiles_per_launch": tiles_per_launch(a, ops, path),
                        "warmup_note": "the warm-up tiles run twice on each in-flight stream",
                        "parallelism": f"image-sharded x{world}", "path": a.path},
-            "single_tile_ms": round(single_ms, 3),
-            "single_tile_encode_ms": round(single_enc_ms, 3), "single_tile_decode_ms": round(single_dec_ms, 3),
-            "single_tile_mpixels_per_s": round(px / single_ms / 1e3, 4),
+            "single_tile_ms": round(single["ms"], 3),
+            "single_tile_encode_ms": round(single["encode_ms"], 3), "single_tile_decode_ms": round(single["decode_ms"], 3),
+            "single_tile_mpixels_per_s": round(px / single["ms"] / 1e3, 4),
             "single_tile_note": "one tile alone on one GPU (nothing else in flight), encode fit | truncation + decode, median of 3; "
                                 "`value` is the throughput with tiles_in_flight_per_gpu independent tiles progressing together",
+            "timed_equals_lone": timed_equals_lone,
+            "timed_equals_lone_note": "the last timed tile's fit (as the timed region ran it: fits stepping in pairs per launch, "
+                                      "several in flight) against the same tile fitted alone afterwards: best weights and decoded "
+                                      "raster compared bit for bit",
             "recon_mse_last_tile": round(mse, 4),
             "recon_psnr_last_tile": round(10 * np.log10(10000 ** 2 / max(mse, 1e-12)), 3),
             "records": records,
         }
         out["roofline"] = roofline_probe(codec, ops, fit, img_d, a, path)
         # whole job against the matrix peak: algorithmic FLOPs of every timed tile (10 train + 10 evaluation passes + decode)
-        fwd_f, _ = flops_per_pixel(fit.geom.F, fit.net.bc, fit.net.C, fit.net.nl)
-        _, step_f = flops_per_pixel(out["roofline"].get("features_multiplied", fit.geom.F), fit.net.bc, fit.net.C, fit.net.nl)
-        evals = a.epochs if a.epochs > 1 else 0
-        tile_flop = px * (a.epochs * step_f + (evals + 1) * fwd_f)
+        tile_flop = tile_flops(a, ops, fit, path)
         out["roofline"]["end_to_end_tflops"] = round(tile_flop * a.steps * world / elapsed / 1e12, 3)
         out["roofline"]["end_to_end_frac"] = round(tile_flop * a.steps / elapsed / 1e12 / 157.3, 4)
+        out["roofline"]["single_tile_end_to_end_frac"] = round(tile_flop / (single["ms"] * 1e-3) / 1e12 / 157.3, 4)
+        del single, lone, lone_rec
+        if world == 1 and not a.no_other_configs and config_key(a) == "bc64" and a.height == 2048 and a.width == 2048 \
+                and a.path == "auto":
+            # BASELINE.json configs[2] and configs[4], a short leg each in the same call (the headline above is unchanged)
+            out["other_configs"] = {
+                "bc256": side_leg(codec, ops, tiles, a, path, bc=256, in_flight=2, steps=4, warmup=2,
+                                  label="BASELINE.json configs[2]: the same tile, bc = 256 (k_train_wide / k_apply_wide)"),
+                "embed": side_leg(codec, ops, tiles, a, path, coords_embedding=True, in_flight=4, steps=8, warmup=4,
+                                  label="BASELINE.json configs[4]: USE_COORDINATES + EMBEDDING (F = 250)"),
+            }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))

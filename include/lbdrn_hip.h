@@ -173,7 +173,10 @@ int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom *const *g, const lbd
  * Timing one epoch in each mode with a single HIP-event pair gives, per step, t_reduce = t(mode 1) - t(mode 0) and
  * t_train = t(mode 2) - t(mode 0) -- what one more launch of that kernel costs inside the real dependent sequence,
  * its launch boundary included -- without per-launch event packets (which cost more than the gaps they would
- * measure).  Use on scratch optimiser state. */
+ * measure).  mode 3: the reduce/Adam launch is left out -- an epoch of training launches back to back, every one on its
+ * own slice of the permutation (cold rows, unlike the repeated launch of mode 2): t(mode 3) / steps is the training
+ * kernel's own average duration, the figure bench.py's `roofline.achieved` is computed from.  Use on scratch optimiser
+ * state. */
 int lbdrn_train_profile_mode(int32_t mode);
 
 /* a4 -- the minibatch order: perm[0..n) = torch.randperm(n, generator=torch.Generator().manual_seed(seed))

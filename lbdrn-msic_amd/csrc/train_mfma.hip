@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256)
     // table entry .y; -3: column table entry .y; -4: label of channel .y
     __syncthreads();   // window and offset tables are in LDS
     const bool rel = g.relative && g.D > 0;
-    int2* ptab = reinterpret_cast<int2*>(cto + ncolor + ((ncolor & 1) ? 1 : 0));   // [RP], 8-byte aligned
+    int2* ptab = reinterpret_cast<int2*>(cto + ncolor);   // [RP]; 8-byte aligned as it stands: C side SW (SW = 32 + 2 D) and 2 ncolor are both even
     for (int pos = tid; pos < RP; pos += 256) {
         const int f = row_source(pos, LQs, F, g.C, fm);
         int2 t = make_int2(-1, 0);
@@ -1076,7 +1076,8 @@ static int configure_lds_once(K kern, int bytes, std::atomic<unsigned long long>
     return 0;
 }
 
-// measurement aid (see lbdrn_hip.h): mode 1 doubles the reduce/Adam launch of every step, mode 2 the training launch
+// measurement aid (see lbdrn_hip.h): mode 1 doubles the reduce/Adam launch of every step, mode 2 the training launch,
+// mode 3 leaves the reduce/Adam launch out (an epoch of training launches back to back, each on its own rows)
 static thread_local int g_prof_mode = 0;
 int train_profile_mode(int mode)
 {
@@ -1207,7 +1208,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     LBDRN_REQUIRE((total + 255) / 256 < ((int64_t)1 << 31), "image too large for one launch");
     const int side = 2 * g.D + 1;
     const size_t ncol = (size_t)std::max(net.F - 2 * g.P, 0);
-    const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + (ncol & 1) + 2 * (size_t)p.RP) * 4;   // window + offsets + position table
+    const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + 2 * (size_t)p.RP) * 4;   // window + offsets + position table
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
         k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
@@ -1322,8 +1323,9 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
             if (int rc = dispatch_train(A, nwg, count, s)) return rc;
         ++step;
         const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
-        k_reduce_adam<<<red_grid, 256, 0, s>>>(R, nwg, A.p.slab_floats, map, (float)(lr / bc1), (float)std::sqrt(bc2),
-                                               (double)B * net.C);
+        if (g_prof_mode != 3)   // (mode 3, measurement only: the training launches alone, every one on its own slice of rows)
+            k_reduce_adam<<<red_grid, 256, 0, s>>>(R, nwg, A.p.slab_floats, map, (float)(lr / bc1), (float)std::sqrt(bc2),
+                                                   (double)B * net.C);
         if (g_prof_mode == 1) {  // measurement only: the same launch again with a zero step
             ReduceArgs R0 = R;
             for (int f = 0; f < MAX_GROUP; ++f) R0.fit[f].loss_out = nullptr;

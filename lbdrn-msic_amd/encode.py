@@ -114,7 +114,13 @@ def main(argv=None, shard_tiles=None):
     """shard_tiles: spread the split_ratio tiles over the ranks of a torchrun launch (default: whenever
     WORLD_SIZE > 1; sweep.py passes False because it shards whole jobs instead)."""
     global DEVICE
-    args = build_parser().parse_args(argv)
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if os.environ.get("LBDRN_WEIGHTS_CODEC") != "fpzip":
+        try:   # a precision the payload coder refuses is refused here, not after the fit (ADVICE round 3)
+            container.check_weight_precision(args.precision)
+        except ValueError as e:
+            parser.error(str(e))
     rank, world = 0, 1
     if shard_tiles is None:
         shard_tiles = shard.env_world()[1] > 1

@@ -85,6 +85,18 @@ def unflatten_state(flat, like_state_dict):
     return out
 
 
+WEIGHT_PRECISIONS = (0,) + tuple(range(9, 33))   # what the weight payload coder takes (0 = 32 = lossless)
+
+
+def check_weight_precision(precision):
+    """Refuse a `-prec` the weight payload coder will refuse -- BEFORE a fit is spent on it (encode.py / sweep.py call
+    this when they parse their arguments; the coder itself refuses the same set: lbdrn_weights_encode).  fpzip codes precisions 1..8 with a
+    narrow residual coder that this package does not restate (csrc/weights_codec.hip)."""
+    if precision not in WEIGHT_PRECISIONS:
+        raise ValueError(f"-prec {precision}: the weight payload coder takes 0 (lossless) or 9..32 bits")
+    return precision
+
+
 def truncate_precision(flat, precision):
     """The value map of the weight payload: keep the `precision` most significant bits of each float32 pattern
     (sign, exponent, leading mantissa bits), clear the rest; precision 0 or 32 = lossless.  This IS fpzip's lossy

@@ -57,6 +57,12 @@ def parse(argv=None):
         a.D, a.base_channel, a.num_layers, a.lr = int(D), int(BC), int(NL), LR
         a.batch_size, a.epochs, a.split_ratio, a.output_dir = int(BS), int(EPOCH), int(SR), OUT
     a.images = a.images if a.images else list(REFERENCE_IMAGES)
+    if os.environ.get("LBDRN_WEIGHTS_CODEC") != "fpzip":
+        from lbdrn_hip import container
+        try:   # before any fit of the sweep starts
+            container.check_weight_precision(a.precision)
+        except ValueError as e:
+            raise SystemExit(str(e))
     return a
 
 

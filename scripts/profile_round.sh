@@ -1,5 +1,6 @@
 #!/bin/bash
 # Profile pass of a round, run ON the GPU box (gpurun): scripts/profile_round.sh TAG [kt|cfg|pmc|sq ...]
+#   kta  the training launch of bc256 / embed / embed pairs alone on the device; ink  in-kernel stamps + timeline JSON
 #   kt   rocprofv3 --kernel-trace --stats of bench.py with one fit in flight and with the default (four, as two pairs),
 #        and of one pair of fits alone (scripts/prof_pair.py)
 #   cfg  the same for BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING)
@@ -9,7 +10,7 @@
 # Small CSVs land under gpurun_out/prof_TAG/; the databases are deleted as soon as they are summarised.
 # (the program itself follows `--`: the profiler's library has initialised the GPU by then)
 TAG=${1:-r03}; shift
-WHAT=${@:-kt cfg pmc sq}
+WHAT=${@:-kt kta cfg pmc sq ink}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -28,6 +29,15 @@ kt)
   summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py
   rocprofv3 --kernel-trace --stats -d $OUT/ktp -o run -- python3 scripts/prof_pair.py 2048 4 > $OUT/pair_alone.txt 2> $OUT/ktp.err
   summarise $OUT/ktp $OUT/kernel_stats_pair_alone.csv scripts/rocprof_kernel_stats.py ;;
+kta)  # the training launch of every configuration ALONE on the device (one chain): what bench.py's rocprof_kernel_us cites
+  rocprofv3 --kernel-trace --stats -d $OUT/kta_bc256 -o run -- python3 scripts/prof_fit.py 2048 256 2 > $OUT/alone_bc256.txt 2> $OUT/kta_bc256.err
+  summarise $OUT/kta_bc256 $OUT/kernel_stats_alone_bc256.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/kta_embed -o run -- python3 scripts/prof_fit.py 2048 64 3 embed > $OUT/alone_embed.txt 2> $OUT/kta_embed.err
+  summarise $OUT/kta_embed $OUT/kernel_stats_alone_embed.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/kta_embedp -o run -- python3 scripts/prof_pair.py 2048 3 embed > $OUT/pair_alone_embed.txt 2> $OUT/kta_embedp.err
+  summarise $OUT/kta_embedp $OUT/kernel_stats_pair_alone_embed.csv scripts/rocprof_kernel_stats.py ;;
+ink)  # in-kernel stamps / timeline as JSON (diagnostic builds; scripts/collect_inkernel.py)
+  python3 scripts/collect_inkernel.py $TAG > $OUT/inkernel.log 2>&1; echo "ink rc=$?" >> $OUT/status.txt ;;
 cfg)
   rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline -bc 256 --in-flight 2 --steps 2 --repeats 1 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
   summarise $OUT/kt_bc256 $OUT/kernel_stats_bc256.csv scripts/rocprof_kernel_stats.py

@@ -11,8 +11,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 bands = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 nl = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+group = int(sys.argv[5]) if len(sys.argv) > 5 else 1     # fits per launch (codec.fit_many: 2 = pairs)
 dev = torch.device("cuda:0")
 imgs = [ops.to_device_u16(synthetic_tile(i, bands, 2048, 2048), dev) for i in range(2 * n)]
-codec.fit_many(imgs, 5, 2, 64, nl, 1e-3, 8192, epochs, seed=19920517, in_flight=n, group=1)
+codec.fit_many(imgs, 5, 2, 64, nl, 1e-3, 8192, epochs, seed=19920517, in_flight=n, group=group)
 torch.cuda.synchronize()
 print("done")

@@ -256,6 +256,29 @@ def test_payload_round_trips_and_precision_model():
     assert all(torch.equal(sd[k], v) for k, v in m.state_dict().items())
 
 
+def test_precision_the_coder_refuses_is_refused_before_any_fit(tmp_path, monkeypatch):
+    """`-prec 8` used to spend the whole fit and then raise in encode_weights.  One shared range
+    (container.WEIGHT_PRECISIONS) for the CLI parsers and the coder; the parsers stop before any image is opened."""
+    from lbdrn_hip import container as c
+    import encode
+    import sweep
+    monkeypatch.delenv("LBDRN_WEIGHTS_CODEC", raising=False)
+    for good in (0, 9, 16, 32):
+        assert c.check_weight_precision(good) == good
+    for bad in (-1, 1, 2, 8, 33):
+        with pytest.raises(ValueError):
+            c.check_weight_precision(bad)
+        with pytest.raises((ValueError, __import__("lbdrn_hip")._lib.LbdrnError)):   # the coder's own refusal: same set
+            c.encode_weights(np.zeros(4, np.float32), bad)
+    missing = str(tmp_path / "never_opened.tif")          # the parser must stop before it looks at the image
+    with pytest.raises(SystemExit) as e:
+        encode.main(["-i", missing, "-o", str(tmp_path), "-prec", "8"], shard_tiles=False)
+    assert e.value.code == 2
+    with pytest.raises(SystemExit):
+        sweep.parse(["--images", missing, "-prec", "5"])
+    assert not any(tmp_path.iterdir())                     # no output directory, no log
+
+
 def test_raster_io_round_trip(tmp_path):
     from lbdrn_hip import raster_io as r
     rng = np.random.default_rng(1)
