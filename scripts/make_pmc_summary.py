@@ -35,11 +35,11 @@ for f in sorted(os.listdir(src)):
     if f.endswith((".csv", ".json")) and not f.startswith("."):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 # (apply_eval: the evaluation pass as a fit runs it -- MODE_EVAL_FAST = 2; the canonical MODE_EVAL = 1 pass where a run used it)
-KERNELS = {"bc64": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+KERNELS = {"bc64": {"train": "k_train_stream<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
            "bc256": {"train": "k_train_wide", "reduce": "k_reduce_adam", "apply_eval": "k_apply_wide<16, 2, 2>", "apply_decode": "k_apply_wide<16, 2, 0>"},
-           "embed": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+           "embed": {"train": "k_train_stream<64", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
            # the launches of a PAIR of bc64 fits stepping side by side (scripts/prof_pair.py): 2 x 128 workgroups, every CU
-           "pair": {"train": "k_train_stream", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>"}}
+           "pair": {"train": "k_train_stream<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>"}}
 # MI355X_MICROARCH.md, HBM: "on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B per
 # lane, global_load and buffer_load ... lds alike)" -- so the doubling applies to the kernels whose fetches ARE such reads
 # (rows by LDS-DMA, fragments / weights / slabs as 16-byte loads) and NOT to the apply kernels, which fetch two uint16 planes
@@ -138,5 +138,17 @@ for extra in ("timeline_bc64_two_chains.json", "timeline_pair_two_chains.json"):
     if j and j.get("per_step_us"):
         out.setdefault("timeline_in_flight", {})[extra[len("timeline_"):-len(".json")]] = {
             "what": j["what"], "per_step_us": j["per_step_us"], "source": f"profiles/{tag}_{extra}"}
-json.dump(out, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+# a partial re-collection (e.g. kernel traces and in-kernel summaries only) keeps the counter entries of the previous
+# summary, each marked with where it came from
+old_path = os.path.join(dst, "pmc_summary.json")
+if os.path.exists(old_path):
+    old = json.load(open(old_path))
+    for cfg, oc in old.get("configs", {}).items():
+        nc = out["configs"].setdefault(cfg, {})
+        for k, v in oc.items():
+            if k not in nc:
+                if isinstance(v, dict) and "carried_over_from" not in v:
+                    v = dict(v, carried_over_from=old.get("source", "an earlier summary")[:160])
+                nc[k] = v
+json.dump(out, open(old_path, "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -23,9 +23,9 @@ declare -A PROG=( [bc64]="scripts/prof_fit.py 2048 64 4" [bc256]="scripts/prof_f
 CFGS=${CFGS:-bc64 bc256 embed pair}
 for W in $WHAT; do case $W in
 kt)
-  rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- python3 bench.py --no-cpu-baseline --in-flight 1 --steps 1 --warmup 0 --repeats 1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt1 -o run -- python3 bench.py --no-cpu-baseline --no-other-configs --in-flight 1 --steps 1 --warmup 0 --repeats 1 > $OUT/bench_one_in_flight.json 2> $OUT/kt1.err
   summarise $OUT/kt1 $OUT/kernel_stats_one_in_flight.csv scripts/rocprof_kernel_stats.py
-  rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline --repeats 1 > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt4 -o run -- python3 bench.py --no-cpu-baseline --no-other-configs --repeats 1 > $OUT/bench_four_in_flight.json 2> $OUT/kt4.err
   summarise $OUT/kt4 $OUT/kernel_stats_four_in_flight.csv scripts/rocprof_kernel_stats.py
   rocprofv3 --kernel-trace --stats -d $OUT/ktp -o run -- python3 scripts/prof_pair.py 2048 4 > $OUT/pair_alone.txt 2> $OUT/ktp.err
   summarise $OUT/ktp $OUT/kernel_stats_pair_alone.csv scripts/rocprof_kernel_stats.py ;;
@@ -39,9 +39,9 @@ kta)  # the training launch of every configuration ALONE on the device (one chai
 ink)  # in-kernel stamps / timeline as JSON (diagnostic builds; scripts/collect_inkernel.py)
   python3 scripts/collect_inkernel.py $TAG > $OUT/inkernel.log 2>&1; echo "ink rc=$?" >> $OUT/status.txt ;;
 cfg)
-  rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline -bc 256 --in-flight 2 --steps 2 --repeats 1 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_bc256 -o run -- python3 bench.py --no-cpu-baseline --no-other-configs -bc 256 --in-flight 2 --steps 2 --repeats 1 > $OUT/bench_bc256.json 2> $OUT/kt_bc256.err
   summarise $OUT/kt_bc256 $OUT/kernel_stats_bc256.csv scripts/rocprof_kernel_stats.py
-  rocprofv3 --kernel-trace --stats -d $OUT/kt_embed -o run -- python3 bench.py --no-cpu-baseline --coords-embedding --steps 4 --repeats 1 > $OUT/bench_embed.json 2> $OUT/kt_embed.err
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_embed -o run -- python3 bench.py --no-cpu-baseline --no-other-configs --coords-embedding --steps 4 --repeats 1 > $OUT/bench_embed.json 2> $OUT/kt_embed.err
   summarise $OUT/kt_embed $OUT/kernel_stats_embed.csv scripts/rocprof_kernel_stats.py ;;
 pmc)
   for CFG in $CFGS; do for C in FETCH_SIZE WRITE_SIZE; do
