@@ -175,8 +175,10 @@ int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom *const *g, const lbd
  * its launch boundary included -- without per-launch event packets (which cost more than the gaps they would
  * measure).  mode 3: the reduce/Adam launch is left out -- an epoch of training launches back to back, every one on its
  * own slice of the permutation (cold rows, unlike the repeated launch of mode 2): t(mode 3) / steps is the training
- * kernel's own average duration, the figure bench.py's `roofline.achieved` is computed from.  Use on scratch optimiser
- * state. */
+ * kernel's own average duration, the figure bench.py's `roofline.achieved` is computed from.  Where a step has TWO
+ * launches in front of its reduce/Adam launch (the bc >= 128 step: forward/backward, then the weight-gradient GEMM) mode 3
+ * runs both, mode 4 the forward/backward launch alone and mode 5 doubles the weight-gradient launch; elsewhere mode 4 is
+ * mode 3 and mode 5 is mode 0.  Use on scratch optimiser state. */
 int lbdrn_train_profile_mode(int32_t mode);
 
 /* a4 -- the minibatch order: perm[0..n) = torch.randperm(n, generator=torch.Generator().manual_seed(seed))

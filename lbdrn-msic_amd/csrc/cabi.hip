@@ -294,7 +294,7 @@ int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom* const* g, const lbd
 
 int lbdrn_train_profile_mode(int32_t mode)
 {
-    LBDRN_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0, 1, 2 or 3");
+    LBDRN_REQUIRE(mode >= 0 && mode <= 5, "mode must be 0 .. 5");
     return train_profile_mode(mode);
 }
 

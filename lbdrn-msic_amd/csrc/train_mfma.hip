@@ -520,7 +520,11 @@ struct ReduceFit {
     const double* loss_part;
     float* loss_out;
 };
-struct ReduceArgs { ReduceFit fit[MAX_GROUP]; unsigned long long* tl; };
+struct ReduceArgs {
+    ReduceFit fit[MAX_GROUP];
+    unsigned long long* tl;
+    int nloss;   // loss partials per fit (one per training workgroup; the slab count is the kernel's nwg argument)
+};
 
 __global__ void __launch_bounds__(256)
     k_reduce_adam(ReduceArgs R, int nwg, int slab_floats, const int4* __restrict__ map, float step_size, float bc2_sqrt,
@@ -587,7 +591,7 @@ __global__ void __launch_bounds__(256)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && F.loss_out) {
         double s = 0.0;
-        for (int k = 0; k < nwg; ++k) s += F.loss_part[k];
+        for (int k = 0; k < R.nloss; ++k) s += F.loss_part[k];
         *F.loss_out = (float)(s / loss_count);
     }
 #ifdef LBDRN_TIMELINE
@@ -1077,7 +1081,9 @@ static int configure_lds_once(K kern, int bytes, std::atomic<unsigned long long>
 }
 
 // measurement aid (see lbdrn_hip.h): mode 1 doubles the reduce/Adam launch of every step, mode 2 the training launch,
-// mode 3 leaves the reduce/Adam launch out (an epoch of training launches back to back, each on its own rows)
+// mode 3 leaves the reduce/Adam launch out (an epoch of training launches back to back, each on its own rows); the split
+// wide step (train_wide.inc) has two launches in front of the reduce: mode 3 runs both, mode 4 the forward/backward launch
+// alone, mode 5 doubles the weight-gradient launch
 static thread_local int g_prof_mode = 0;
 int train_profile_mode(int mode)
 {
@@ -1323,7 +1329,8 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
             if (int rc = dispatch_train(A, nwg, count, s)) return rc;
         ++step;
         const double bc1 = 1.0 - std::pow(0.9, (double)step), bc2 = 1.0 - std::pow(0.999, (double)step);
-        if (g_prof_mode != 3)   // (mode 3, measurement only: the training launches alone, every one on its own slice of rows)
+        R.nloss = nwg;
+        if (g_prof_mode != 3 && g_prof_mode != 4)   // (modes 3 / 4, measurement only: the training launches alone, every one on its own slice of rows)
             k_reduce_adam<<<red_grid, 256, 0, s>>>(R, nwg, A.p.slab_floats, map, (float)(lr / bc1), (float)std::sqrt(bc2),
                                                    (double)B * net.C);
         if (g_prof_mode == 1) {  // measurement only: the same launch again with a zero step
