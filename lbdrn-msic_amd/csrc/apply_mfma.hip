@@ -50,6 +50,10 @@ struct ApplyPlan {
     int TH;          // tile rows
     int SH, SW;      // staged rows / pitch = TH+2D, TILE_W+2D
     int ncolor;      // colour features = F - 2P
+    int pair;        // 1: the tolerance-arithmetic pass walks the colour features in CHANNEL PAIRS (k_apply_mfma, layer0_pair):
+                     // step (c, r) multiplies window position r of channel c in lane half 0 and of channel c + C/2 in lane
+                     // half 1; with RELATIVE the window centre -- an exact zero -- is not a step
+    int RS;          // pair: steps per channel pair = (2D+1)^2, minus the centre with RELATIVE
     // float offsets inside the packed buffer == inside LDS
     int off_w0, off_wh, off_wl, off_bh, off_bl, pack_floats;
     // further LDS regions (float offsets)
@@ -57,7 +61,7 @@ struct ApplyPlan {
     int tiles_x, tiles_y;
 };
 
-static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p)
+static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, bool fast = false)
 {
     if (net.bc % 32 != 0 || net.bc < 32 || net.bc > 128) return false;
     if (net.C > 32 || net.nl < 1 || net.nl > 15) return false;
@@ -66,6 +70,14 @@ static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p)
     q.ncolor = net.F - 2 * g.P;
     if (q.ncolor < 0) return false;
     q.S0 = g.P + ((q.ncolor + 1) / 2 + 3) / 4 * 4;
+    // the evaluation pass in the tolerance arithmetic may take the features in any order (the sum is held to 1e-6, not to
+    // a bit pattern): channel pairs, and no step for the window centres, which are exact zeros with RELATIVE
+    // (LBDRNdataset.py:126-128) -- 96 MFMA steps instead of 100 at the headline shape.  LBDRN_EVAL_NOPAIR=1: A/B
+    static const bool nopair = getenv("LBDRN_EVAL_NOPAIR") != nullptr;
+    const int side = 2 * g.D + 1;
+    q.pair = fast && !nopair && g.use_colors && g.D >= 1 && g.D <= 3 && (g.C % 2) == 0 && q.ncolor == g.C * side * side;
+    q.RS = side * side - ((g.relative && g.D > 0) ? 1 : 0);
+    if (q.pair) q.S0 = g.P + (g.C / 2) * q.RS;
     const int half = net.bc / 2;
     int o = 0;
     q.off_w0 = o; o += q.S0 * 64 * q.NT;
@@ -118,7 +130,7 @@ size_t mfma_apply_workspace(const lbdrn_geom& g, const lbdrn_net& net)
 
 // params (state_dict order) -> fragment order; one thread per packed float
 __global__ void __launch_bounds__(256)
-    k_pack_apply(const float* __restrict__ params, lbdrn_net net, ApplyPlan p, float* __restrict__ out)
+    k_pack_apply(const float* __restrict__ params, lbdrn_net net, ApplyPlan p, int P, int C, float* __restrict__ out)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.pack_floats) return;
@@ -127,6 +139,11 @@ __global__ void __launch_bounds__(256)
     if (e < p.off_wh) {  // layer 0: [S0][64][NT]
         int t = e % NT, lane = (e / NT) % 64, s = e / (NT * 64);
         int k = 2 * s + (lane >> 5);
+        if (p.pair && s >= P) {   // step (c, r'): channel c + (C/2) * lane half, window position r' (the centre left out)
+            const int s2 = (p.ncolor / C), sp = s - P, c = sp / p.RS, rr = sp - c * p.RS;
+            const int r = rr + ((p.RS < s2 && rr >= s2 / 2) ? 1 : 0);
+            k = 2 * P + (c + (lane >> 5) * (C / 2)) * s2 + r;
+        }
         int neuron = tile_row_to_neuron(lane & 31) + 32 * t;
         if (k < net.F) v = params[(int64_t)neuron * net.F + k];
     } else if (e < p.off_wl) {  // hidden layers 1..nl-1: [l-1][half][64][NT]
@@ -204,6 +221,35 @@ __device__ __forceinline__ void load_a(const float* w, int idx, float (&a)[NT])
         float4 v = *reinterpret_cast<const float4*>(w + (size_t)idx * 4);
         a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
     }
+}
+
+// Layer 0 of the tolerance-arithmetic evaluation pass over the colour features, in channel pairs (ApplyPlan::pair): lane
+// half h walks the window of channel c + h C/2, so one per-lane base address serves every step of a pair and what
+// changes from step to step is a compile-time offset: per step ONE LDS read of the window (the canonical loop reads an
+// offset pair out of a table, the neighbour AND the centre: three reads), the centre of the pair's channel is read once
+// and held in a register, and the window centre itself -- centre minus centre, an exact zero -- is not a step.
+// wc: the pair's first fragment (w0 + ((P + c RS) 64 + lane) NT); tp: tile + c plane + (h C/2) plane + ly SW + lx + j.
+template <int NT, int D, bool REL>
+__device__ __forceinline__ void layer0_pair(f32x16 (&acc)[NT], const float* wc, const float* tp)
+{
+    constexpr int side = 2 * D + 1, S2 = side * side, CEN = D * side + D, SW = TILE_W + 2 * D, RS = S2 - (REL ? 1 : 0);
+    const float cen = tp[D * SW + D];
+    float bq[RS];
+#pragma unroll
+    for (int r = 0; r < S2; ++r) {
+        if (REL && r == CEN) continue;
+        const float nb = tp[(r / side) * SW + (r % side)];
+        bq[r - ((REL && r > CEN) ? 1 : 0)] = REL ? nb - cen : nb;   // minus centre, LBDRNdataset.py:126-128
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < RS; ++k) {
+        float a[NT];
+        load_a<NT>(wc, k * 64, a);
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], bq[k], acc[tt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int NT, int MODE>
@@ -291,7 +337,10 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                         row = e / p.SW; sx = e - row * p.SW; c = row / p.SH; sy = row - c * p.SH;
                         yy = reflect_idx(y0 + sy - D, g.H); xx = reflect_idx(x0 + sx - D, g.W);
                     }
-                    raw[u] = A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx];
+                    // (the fast evaluation pass is internal to a fit, whose MSB plane IS img >> K: one plane read per pass
+                    //  instead of two; the API's canonical pass and the decode pass read the plane they are given)
+                    raw[u] = MODE == MODE_EVAL_FAST ? (unsigned short)(A.img[(int64_t)c * HW + (int64_t)yy * g.W + xx] >> g.K)
+                                                    : A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx];
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
@@ -350,6 +399,27 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                 for (int tt = 0; tt < NT; ++tt)
                     acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], b, acc[tt], 0, 0, 0);
             }
+            bool paired = false;
+            if constexpr (MODE == MODE_EVAL_FAST) {
+                if (p.pair) {
+                    paired = true;
+                    const int plane = p.SH * p.SW;
+                    const float* tp = tile + h * (C / 2) * plane + ly * p.SW + lx + j;
+                    const float* wc = w0 + ((size_t)P * 64 + lane) * NT;
+                    for (int c = 0; c < C / 2; ++c, tp += plane, wc += (size_t)p.RS * 64 * NT) {
+                        if (rel) {
+                            if (D == 1) layer0_pair<NT, 1, true>(acc, wc, tp);
+                            else if (D == 2) layer0_pair<NT, 2, true>(acc, wc, tp);
+                            else layer0_pair<NT, 3, true>(acc, wc, tp);
+                        } else {
+                            if (D == 1) layer0_pair<NT, 1, false>(acc, wc, tp);
+                            else if (D == 2) layer0_pair<NT, 2, false>(acc, wc, tp);
+                            else layer0_pair<NT, 3, false>(acc, wc, tp);
+                        }
+                    }
+                }
+            }
+            if (!paired) {
 #if LBDRN_APPLY_CHUNK > 0
             // colour features in chunks of CH steps: the chunk's B operands (window gather, minus centre) are all made
             // first -- vector and LDS work only --, then its 2 CH MFMAs run with nothing but their A-operand reads
@@ -400,6 +470,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                     for (int tt = 0; tt < NT; ++tt)
                         acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u][tt], bq[u], acc[tt], 0, 0, 0);
             }
+            }   // !paired
             ASTAMP(1);  // layer 0
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
@@ -625,7 +696,7 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
                      double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
 {
     ApplyArgs A;
-    if (!make_plan(g, net, &A.p))   // too wide for LDS-resident weights: the streaming kernel (apply_wide.inc)
+    if (!make_plan(g, net, &A.p, mode == MODE_EVAL_FAST))   // too wide for LDS-resident weights: the streaming kernel (apply_wide.inc)
         return run_wapply(g, net, mode, img, msb, params, out, y_out, sse, ws, ws_bytes, background, s);
     if (!ws || ws_bytes < mfma_apply_workspace(g, net)) {
         set_error("apply workspace too small: %zu < %zu", ws_bytes, mfma_apply_workspace(g, net));
@@ -633,7 +704,7 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
     }
     float* packed = (float*)ws;
     double* partial = (double*)((char*)ws + align_up((size_t)A.p.pack_floats * 4, 256));
-    k_pack_apply<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, packed);
+    k_pack_apply<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, g.P, g.C, packed);
     LBDRN_LAUNCH_CHECK();
     A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
     A.partial = partial;
