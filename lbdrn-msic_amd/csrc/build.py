@@ -18,6 +18,31 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+JP2_OUT = os.path.join(os.path.dirname(HERE), "liblbdrn_jp2.so")
+
+
+def build_jp2(force=False):
+    """liblbdrn_jp2.so (include/lbdrn_jp2.h): OpenJPEG behind a C ABI, gcc, host only.  Built where openjpeg.h and
+    libopenjp2 are found (this image: /opt/conda); returns None elsewhere -- the JPEG 2000 payload is then unavailable
+    and says so, the default GPU payload does not need it."""
+    import glob
+    src = os.path.join(HERE, "jp2_shim.c")
+    hdr = os.path.join(HERE, "..", "..", "include", "lbdrn_jp2.h")
+    if not force and os.path.exists(JP2_OUT) and os.path.getmtime(JP2_OUT) > max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        return JP2_OUT
+    for root in ("/opt/conda", "/usr", "/usr/local"):
+        incs = sorted(glob.glob(os.path.join(root, "include", "openjpeg-*", "openjpeg.h")))
+        libs = [d for d in (os.path.join(root, "lib"), os.path.join(root, "lib", "x86_64-linux-gnu"))
+                if glob.glob(os.path.join(d, "libopenjp2.so*"))]
+        if incs and libs:
+            lib = sorted(glob.glob(os.path.join(libs[0], "libopenjp2.so*")))[0]
+            cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.dirname(incs[-1]), "-o", JP2_OUT, src,
+                   lib, "-Wl,-rpath," + libs[0]]
+            subprocess.check_call(cmd)
+            return JP2_OUT
+    return None
+
+
 def stale():
     if not os.path.exists(OUT):
         return True
@@ -56,3 +81,4 @@ if __name__ == "__main__":
                     out=os.path.join(os.path.dirname(HERE), f"liblbdrn_hip_{sys.argv[k + 1]}.so")))
     else:
         print(build(force="--force" in sys.argv))
+        print(build_jp2(force="--force" in sys.argv) or "liblbdrn_jp2.so: OpenJPEG not found, not built")

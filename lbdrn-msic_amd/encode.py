@@ -24,7 +24,8 @@ from lbdrn_hip.features import FeatCfg
 from LBDRNdataset import tile_windows
 
 DEVICE = "cuda:0"
-BASE_CODEC = os.environ.get("LBDRN_BASE_CODEC", "LBB2")   # "LBB1": the portable host payload of older files
+BASE_CODEC = os.environ.get("LBDRN_BASE_CODEC", "LBB2")   # "jp2": JPEG 2000 through OpenJPEG, what the reference writes
+                                                          # (encode.py:137); "LBB1": the portable host payload of older files
 IN_FLIGHT = int(os.environ["LBDRN_IN_FLIGHT"]) if "LBDRN_IN_FLIGHT" in os.environ else None   # tiles of one image
 # progressing at a time on a GPU (None: codec.fit_many's default, 4)
 

@@ -8,9 +8,13 @@ The two payload codecs of the reference are third-party programs that are absent
   * weights: an fpzip stream, always written and read by this package's restatement of the published algorithm
     (csrc/weights_codec.hip; byte compatibility with fpzip is unverified here: parity unpinned) and cross-checked
     against the fpzip module wherever that is importable;
-  * MSB plane: always this package's own tagged format (LBB2, coded on the GPU; LBB1, the older host codec): JPEG 2000
-    syntax is not produced or read, with or without GDAL.  bpsp figures are therefore not comparable with the
-    reference's published ones; MSE / PSNR are.
+  * MSB plane: by default this package's own tagged format (LBB2, coded on the GPU in 3.5 ms; LBB1, the older host codec).
+    LBDRN_BASE_CODEC=jp2 writes what the reference writes -- a multi-component reversible (5/3) lossless JPEG 2000 file,
+    through the OpenJPEG library GDAL's JP2OpenJPEG driver wraps (lbdrn_hip/jp2.py, csrc/jp2_shim.c) -- and ANY payload
+    that starts with the JP2 signature box (or a raw codestream marker) is decoded that way, so a base payload written
+    by the reference decodes too.  Pixel values are pinned (the path is lossless); byte identity with a GDAL-written
+    file is not (GDAL is absent: its tiling and box choices cannot be replayed here).  bpsp of an LBB2 file is not
+    comparable with the reference's published figures; that of a jp2 file is, up to those choices.
 DESIGN.md "Container" states what is and is not interchangeable.
 """
 import lzma
@@ -229,6 +233,13 @@ def encode_base(msb, codec="LBB2", device="cuda:0", as_uint8=None):
     or the device tensor the fit left in HBM (then as_uint8 says which dtype the decoder hands back).  LBB1: the portable host codec of earlier bitstreams (plane
     predictor + LZMA; a minute per 8 x 2048^2 tile), kept so that those files still decode and for hosts
     that only need to write small rasters."""
+    if codec.lower() in ("jp2", "jpeg2000", "jp2openjpeg"):   # ref encode.py:137
+        from . import jp2
+        if not isinstance(msb, np.ndarray):
+            from . import ops
+            x = ops.from_device_u16(msb)
+            msb = x.astype(np.uint8) if as_uint8 else x
+        return jp2.encode(msb)
     if codec == "LBB2":
         from . import ops
         if isinstance(msb, np.ndarray):
@@ -259,6 +270,13 @@ def decode_base(buf, device="cuda:0", keep_on_device=False):
     """MSB payload -> [C,H,W] numpy (uint8 / uint16 as encoded).  keep_on_device: an LBB2 payload is returned
     as the device tensor it was decoded into (uint16 bits, int16 storage) -- decode.py feeds it straight to
     the apply kernel."""
+    from . import jp2
+    if jp2.is_jp2(buf):   # a JPEG 2000 payload (LBDRN_BASE_CODEC=jp2, or the reference's own: decode.py:69-73)
+        x = jp2.decode(buf)
+        if keep_on_device:
+            from . import ops
+            return ops.to_device_u16(x.astype(np.uint16), device)
+        return x
     if buf[:4] == BASE_LBB2_MAGIC:
         from . import ops
         code, C, H, W = struct.unpack_from(">BHII", buf, 4)
@@ -268,8 +286,7 @@ def decode_base(buf, device="cuda:0", keep_on_device=False):
         x = ops.from_device_u16(planes)
         return x.astype(np.uint8) if code == 1 else x
     if buf[:4] != BASE_PRIVATE_MAGIC:
-        raise ValueError("MSB payload is not this package's private format (a JPEG 2000 stream "
-                         "written by the reference needs GDAL/OpenJPEG, which is not installed)")
+        raise ValueError("MSB payload is neither a JPEG 2000 stream nor one of this package's tagged formats")
     code, C, H, W = struct.unpack_from(">BHII", buf, 4)
     raw = np.frombuffer(lzma.decompress(bytes(buf[15:])), np.uint8)
     n = C * H * W

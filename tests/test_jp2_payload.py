@@ -1,0 +1,98 @@
+"""The JPEG 2000 MSB payload (ref encode.py:137, decode.py:69-73) through liblbdrn_jp2.so =
+OpenJPEG behind a C ABI.  Host code: the container-level tests run without a GPU, the CLI round trip needs one.
+Skipped where OpenJPEG was not found at build time."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def jp2():
+    from lbdrn_hip import jp2 as mod
+    if not mod.available():
+        pytest.skip("liblbdrn_jp2.so not built (OpenJPEG absent)")
+    return mod
+
+
+def test_jp2_library_exports_every_declared_symbol(jp2):
+    hdr = open(os.path.join(ROOT, "include", "lbdrn_jp2.h")).read()
+    declared = set(re.findall(r"\b(lbdrn_jp2_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == {"lbdrn_jp2_last_error", "lbdrn_jp2_encode", "lbdrn_jp2_info", "lbdrn_jp2_decode", "lbdrn_jp2_free"}
+    L = ctypes.CDLL(jp2._PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_lossless_round_trip_of_multiband_planes(jp2):
+    """uint8 and uint16 planes, one to sixteen bands, sizes below / above the 1024-pixel tile edge, full 16-bit range:
+    decode(encode(x)) == x with the dtype kept (the reference's MSB raster is Byte when max <= 255, LBDRNdataset.py:100)."""
+    from lbdrn_hip import container
+    rng = np.random.default_rng(0)
+    cases = [(np.uint8, 255, (3, 37, 41)), (np.uint16, 312, (8, 70, 90)), (np.uint16, 65535, (1, 5, 7)),
+             (np.uint8, 255, (2, 1100, 1030)), (np.uint16, 2047, (16, 33, 65)), (np.uint8, 1, (4, 1, 9))]
+    for dt, hi, shape in cases:
+        x = rng.integers(0, hi + 1, shape).astype(dt)
+        if shape[1] > 64:   # spatially correlated content as well as noise
+            x[0] = (np.add.outer(np.arange(shape[1]), np.arange(shape[2])) % (hi + 1)).astype(dt)
+        b = jp2.encode(x)
+        assert b[:12] == jp2.SIGNATURE and jp2.is_jp2(b)
+        y = jp2.decode(b)
+        assert y.dtype == dt and np.array_equal(x, y), (dt, shape)
+        # through the container: the payload is recognised by its signature, whatever wrote it
+        z = container.decode_base(container.encode_base(x, codec="jp2"))
+        assert z.dtype == dt and np.array_equal(x, z)
+    flat = np.zeros((2, 64, 64), np.uint16)
+    assert len(jp2.encode(flat)) < 1000      # an all-zero plane costs its headers
+
+
+def test_damaged_and_foreign_streams_are_refused(jp2):
+    from lbdrn_hip import container
+    x = np.arange(3 * 20 * 30, dtype=np.uint16).reshape(3, 20, 30)
+    b = jp2.encode(x)
+    with pytest.raises(jp2.Jp2Error):
+        jp2.decode(b[:len(b) // 2])
+    with pytest.raises(jp2.Jp2Error):
+        jp2.decode(b"not a jpeg 2000 stream at all")
+    with pytest.raises(ValueError):
+        container.decode_base(b"XXXX" + b"\0" * 40)
+    with pytest.raises(ValueError):
+        jp2.encode(np.zeros((1, 4, 4), np.int32))
+
+
+@pytest.mark.gpu
+def test_cli_round_trip_with_the_jpeg2000_payload(jp2, dev, tmp_path):
+    """LBDRN_BASE_CODEC=jp2: encode.py writes the MSB planes as a JP2 file inside the .bin (where the reference's
+    gdal_translate output sits), decode.py recognises it by its signature; the decoded raster equals the one of the default
+    (LBB2) payload bit for bit, the metrics are logged, and the JP2 payload alone decodes to img >> K."""
+    from lbdrn_hip import container, raster_io
+    from lbdrn_hip.synth import synthetic_tile
+    img = synthetic_tile(21, 4, 40, 56)
+    src = tmp_path / "tile.tif"
+    raster_io.write_raster(str(src), img)
+    recs = {}
+    for codec_name in ("jp2", "LBB2"):
+        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"), LBDRN_BASE_CODEC=codec_name)
+        out = tmp_path / codec_name
+        subprocess.run([sys.executable, os.path.join(ROOT, "lbdrn-msic_amd", "encode.py"), "-i", str(src), "-o", str(out),
+                        "-K", "5", "-D", "2", "-bs", "256", "-e", "2"], check=True, env=env, capture_output=True)
+        outdir = out / "tile_r1_K5_bc64_nl2_D2_prec16_lr0.001_bs256_e2"
+        raw = (outdir / "tile.bin").read_bytes()
+        n, sr, w, h, K, bc, nl, D, nn, base = container.unpack_header(raw)
+        payload = raw[n + nn[0]:]
+        assert len(payload) == base[0]
+        assert jp2.is_jp2(payload) == (codec_name == "jp2")
+        msb = container.decode_base(payload)
+        assert np.array_equal(msb, img >> 5) and msb.dtype == np.uint16      # max 312 > 255: UInt16 like the reference's raster
+        import decode as dec_mod
+        sys.argv = ["decode.py"]
+        assert dec_mod.main(["-i", str(outdir / "tile.bin")]) == 0
+        recs[codec_name] = raster_io.read_raster(str(outdir / "tile_recon.tif"))
+        assert re.search(r"MSB: (\d+) bytes", (outdir / "encode.txt").read_text())
+    assert np.array_equal(recs["jp2"], recs["LBB2"]) and np.array_equal(recs["jp2"] >> 5, img >> 5)
