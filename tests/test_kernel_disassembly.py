@@ -1,0 +1,60 @@
+"""Build-time check on the shipped machine code: the loader wave of k_train_stream loads its pixel
+indices with an inline-asm `global_load_dwordx2` and rides the destination through an inline-asm counted wait; between
+the two statements the compiler is free, by the language, to copy or spill that register before the data has landed.
+It does not -- and this test keeps it that way: in the disassembly of every k_train_stream instance, nothing between the
+index load and the first vector-memory wait behind it touches the destination registers, and that wait's count is no
+larger than the LDS-DMA requests issued in between (requests complete in order: the load is then done)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def _regs(token):
+    """'v5' -> {5}; 'v[4:7]' -> {4,5,6,7}"""
+    m = re.fullmatch(r"v(\d+)", token)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", token)
+    return set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else set()
+
+
+def test_loader_wave_index_load_reaches_its_wait_untouched(tmp_path):
+    so = os.path.join(ROOT, "lbdrn-msic_amd", "liblbdrn_hip.so")
+    if not (os.path.exists(OBJDUMP) and os.path.exists(so)):
+        pytest.skip("llvm-objdump or the library is missing")
+    work = tmp_path / "co"
+    work.mkdir()
+    shutil.copy(so, work / "lib.so")
+    subprocess.run([OBJDUMP, "--offloading", "lib.so"], cwd=work, check=True, capture_output=True)   # unbundles next to the input
+    checked = 0
+    for co in sorted(work.glob("lib.so.*gfx950")):
+        syms = subprocess.run([OBJDUMP, "-t", str(co)], capture_output=True, text=True).stdout
+        names = sorted({l.split()[-1] for l in syms.splitlines() if "k_train_stream" in l and " F " in l and l.split()[-1].startswith("_Z")})
+        for name in names:
+            dis = subprocess.run([OBJDUMP, "-d", f"--disassemble-symbols={name}", str(co)], capture_output=True, text=True).stdout
+            lines = [l.split("//")[0].strip() for l in dis.splitlines() if l.startswith("\t")]
+            loads = [k for k, l in enumerate(lines) if l.startswith("global_load_dwordx2")]
+            assert loads, f"{name}: the loader's index load was not found"
+            for k in loads:
+                dst = _regs(lines[k].split()[1].rstrip(","))
+                assert len(dst) == 2, lines[k]
+                dma = 0
+                for l in lines[k + 1:]:
+                    toks = set(re.findall(r"v\[\d+:\d+\]|v\d+", l))
+                    if l.startswith("s_waitcnt") and "vmcnt" in l:
+                        n = int(re.search(r"vmcnt\((\d+)\)", l).group(1))
+                        assert n <= dma, f"{name}: wait for the index load allows {n} requests in flight, only {dma} were issued behind it"
+                        break
+                    assert not any(dst & _regs(t) for t in toks), f"{name}: `{l}` touches the index registers before their wait"
+                    dma += l.startswith("global_load_lds_dwordx4")
+                    assert not l.startswith(("s_endpgm", "s_cbranch", "s_branch")), f"{name}: control flow between the index load and its wait"
+                else:
+                    pytest.fail(f"{name}: no vector-memory wait behind the index load")
+                checked += 1
+    assert checked >= 4, "k_train_stream instances not found in the library's code objects"
