@@ -194,25 +194,39 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
         finally:
             ops.train_profile_mode(0)
         t_epoch = min(t[0])
+        if net.bc > 64 and count == 1:   # the bc >= 128 step has two launches in front of its reduce launch: forward/backward alone
+            ops.train_profile_mode(4)
+            try:
+                split_fb.append(min(event_time_ms(run, stream, 1) for _ in range(2)) / nsteps)
+            finally:
+                ops.train_profile_mode(0)
         return t_epoch / nsteps, min(t[3]) / nsteps, (t[2][0] - t_epoch) / nsteps, (t[1][0] - t_epoch) / nsteps
 
+    split_fb = []
     t_step, t_own, t_train, t_reduce = probe(per_launch)
     fused = t_reduce > 0.5e-3   # a fused MFMA train kernel is in use (the generic path ignores the modes)
-    name = "k_train_wide" if net.bc > 64 else "k_train_stream"
-    nwg = (B + 63) // 64
+    wide = net.bc > 64
+    name = "k_train_half + k_dw_wide" if wide else "k_train_stream"
+    rows_wg = 32 if wide else 64
+    nwg = (B + rows_wg - 1) // rows_wg
     key = config_key(a)
     prof, whole = committed_profile(key if N == 2048 * 2048 else None, per_launch)
     if fused:
         t_k = t_own
-        out.update({"kernel": f"{name} (row gather + forward + loss + backward + weight gradients of one {B}-row "
-                              f"minibatch of {per_launch} fit(s): {per_launch} x {nwg} workgroups of 64 rows, one per CU, on "
-                              f"{min(256, per_launch * nwg)} of the chip's 256 CUs)",
+        out.update({"kernel": (f"{name} (the two training launches of a step: row gather + forward + loss + backward of one {B}-row "
+                               f"minibatch on {nwg} workgroups of 32 rows -- units halved between two waves --, then its weight "
+                               f"gradients as a batch-dimension GEMM on 232 workgroups; every CU)" if wide else
+                               f"{name} (row gather + forward + loss + backward + weight gradients of one {B}-row "
+                               f"minibatch of {per_launch} fit(s): {per_launch} x {nwg} workgroups of 64 rows, one per CU, on "
+                               f"{min(256, per_launch * nwg)} of the chip's 256 CUs)"),
                     "fits_per_launch": per_launch,
                     "kernel_us": round(t_own * 1e3, 2), "marginal_us": round(t_train * 1e3, 2),
                     "reduce_adam_us": round(t_reduce * 1e3, 2),
                     "unaccounted_us": round((t_step - t_train - t_reduce) * 1e3, 2),
                     "flop_per_launch": per_launch * step * B, "flop_per_launch_reference_arithmetic": per_launch * step_ref * B,
                     "features_multiplied": Fe, "cus_occupied": min(256, per_launch * nwg),
+                    **({"forward_backward_us": round(split_fb[0] * 1e3, 2), "weight_gradient_us": round((t_own - split_fb[0]) * 1e3, 2)}
+                       if split_fb else {}),
                     "timing": "HIP events on the launch stream.  kernel_us: one 512-launch epoch of the training launch the "
                               "timed region made (fits_per_launch fits side by side), back to back without the reduce/Adam "
                               "launches, every launch on its own rows (lbdrn_train_profile_mode 3) -- the kernel's own average "
@@ -263,7 +277,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
         out["counters_source"] = whole.get("source")
         kt = prof.get("kernel_trace", {})      # the committed rocprofv3 --kernel-trace --stats average of this launch
         if kt.get("train_avg_us"):
-            r_us = float(kt["train_avg_us"])
+            r_us = float(kt["train_avg_us"]) + float(kt.get("dw_avg_us") or 0.0)   # (bc >= 128: both training launches)
             r_ach = per_launch * step * B / (r_us * 1e-6) / 1e12
             out.update({"rocprof_kernel_us": r_us, "rocprof_kernel_min_us": kt.get("train_min_us"),
                         "rocprof_source": kt.get("source"), "frac_rocprof": round(r_ach / peak, 4),

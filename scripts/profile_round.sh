@@ -46,16 +46,16 @@ cfg)
 pmc)
   for CFG in $CFGS; do for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_${CFG}_$C -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/pmc_${CFG}_$C.err; echo "pmc $CFG $C rc=$?" >> $OUT/status.txt
-    summarise $OUT/pmc_${CFG}_$C $OUT/pmc_${CFG}_$C.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply k_build
+    summarise $OUT/pmc_${CFG}_$C $OUT/pmc_${CFG}_$C.csv scripts/pmc_by_kernel.py k_train k_dw k_reduce k_apply k_build
   done; done ;;
 sq)
   for CFG in $CFGS; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES \
       -d $OUT/sq_a_$CFG -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/sq_a_$CFG.err; echo "sq_a $CFG rc=$?" >> $OUT/status.txt
-    summarise $OUT/sq_a_$CFG $OUT/sq_a_$CFG.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
+    summarise $OUT/sq_a_$CFG $OUT/sq_a_$CFG.csv scripts/pmc_by_kernel.py k_train k_dw k_reduce k_apply
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VMEM \
       -d $OUT/sq_b_$CFG -o run -- python3 ${PROG[$CFG]} > /dev/null 2> $OUT/sq_b_$CFG.err; echo "sq_b $CFG rc=$?" >> $OUT/status.txt
-    summarise $OUT/sq_b_$CFG $OUT/sq_b_$CFG.csv scripts/pmc_by_kernel.py k_train k_reduce k_apply
+    summarise $OUT/sq_b_$CFG $OUT/sq_b_$CFG.csv scripts/pmc_by_kernel.py k_train k_dw k_reduce k_apply
   done ;;
 esac; done
 ls -la $OUT; cat $OUT/status.txt 2>/dev/null
