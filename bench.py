@@ -132,8 +132,13 @@ def committed_profile(key, fits_per_launch):
         d = json.load(open(pmc))
     except Exception:
         return {}, {}
-    ckey = "pair" if key == "bc64" and fits_per_launch == 2 else key
-    return d.get("configs", {}).get(ckey, {}), d
+    cfgs = d.get("configs", {})
+    if key == "bc64" and fits_per_launch == 2:
+        return cfgs.get("pair", {}), d
+    prof = dict(cfgs.get(key, {}))
+    if fits_per_launch == 2 and cfgs.get(key + "_pair", {}).get("kernel_trace"):   # (counters of the single-fit launch, trace of the pair launch)
+        prof["kernel_trace"] = cfgs[key + "_pair"]["kernel_trace"]
+    return prof, d
 
 
 def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single=True):
@@ -639,7 +644,7 @@ def main():
             # BASELINE.json configs[2] and configs[4], a short leg each in the same call (the headline above is unchanged)
             out["other_configs"] = {
                 "bc256": side_leg(codec, ops, tiles, a, path, bc=256, in_flight=3, steps=6, warmup=3,   # (2: 352, 3: 343, 4: 386, 6: 345 ms per tile)
-                                  label="BASELINE.json configs[2]: the same tile, bc = 256 (k_train_wide / k_apply_wide)"),
+                                  label="BASELINE.json configs[2]: the same tile, bc = 256 (k_train_half + k_dw_wide / k_apply_wide)"),
                 "embed": side_leg(codec, ops, tiles, a, path, coords_embedding=True, in_flight=4, steps=8, warmup=4,
                                   label="BASELINE.json configs[4]: USE_COORDINATES + EMBEDDING (F = 250)"),
             }
