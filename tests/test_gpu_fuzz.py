@@ -166,6 +166,60 @@ def test_train_fuzz_mfma_matches_generic(dev):
     assert done >= 6, done
 
 
+def test_wide_train_fuzz_split_step_matches_generic(dev):
+    """The three launches of the bc >= 128 step (k_train_half -> k_dw_wide -> k_reduce_adam) on random shapes: bands 1..16,
+    D 0..3, every constants.py switch, bc 128 / 256, one and two hidden layers, minibatch sizes that leave half-filled
+    32-row workgroups, odd workgroup counts (the zero-filled half block of k_dw_wide), slices of 1024 samples cut short
+    and more than one slice -- losses and first-step Adam moments against the generic path (window gather, one GEMM launch
+    per layer), and bitwise reproducibility of the fused path."""
+    rng = np.random.default_rng(4242)
+    done = 0
+    for it in range(14 * SOAK):
+        C, H, W, K, D, _, _, cfg, img = _random_case(rng, train=True)
+        bc, nl = int(rng.choice([128, 256])), int(rng.integers(1, 3))
+        F = cfg.feature_dim(C, D)
+        msb = img >> K
+        mx = int(msb.max())
+        if mx == 0 or F > 256:
+            continue
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(F, bc, C, nl)
+        p0 = _params(rng, F, bc, C, nl, 1.0)
+        bs = int(rng.choice([33, 96, 257, 1100, 2100]))
+        img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+        order = rng.permutation(H * W).astype(np.int64)
+        tag = (it, C, H, W, K, D, bc, nl, bs, vars(cfg))
+
+        def run(perm_np, path):
+            perm = torch.from_numpy(perm_np).to(dev)
+            nsteps = (len(perm_np) + bs - 1) // bs
+            p = torch.from_numpy(p0.copy()).to(dev)
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            losses = torch.zeros(nsteps, dtype=torch.float32, device=dev)
+            ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 0, 1e-3, losses, path=path)
+            return [t.cpu().numpy() for t in (p, losses, m, v)]
+
+        try:
+            one = order[:int(rng.integers(1, min(bs, H * W) + 1))]       # one (usually ragged) step: exp_avg = 0.1 * gradient
+            pa, la, ma, va = run(one, MFMA)
+            pb, lb, mb, vb = run(one, GEN)
+        except ops._lib.LbdrnError:
+            continue
+        np.testing.assert_allclose(la, lb, rtol=2e-5, err_msg=str(tag))
+        assert np.abs(ma - mb).max() <= 4e-5 * np.abs(mb).max(), tag
+        assert np.abs(va - vb).max() <= 1e-4 * np.abs(vb).max(), tag
+        several = order[:min(len(order), 3 * bs + int(rng.integers(1, bs + 1)))]
+        pa, la, ma, va = run(several, MFMA)
+        pb, lb, mb, vb = run(several, GEN)
+        np.testing.assert_allclose(la, lb, rtol=1e-4, err_msg=str(tag))
+        assert np.isfinite(pa).all(), tag
+        pc, lc, mc, vc = run(several, MFMA)
+        for x, y in ((pa, pc), (la, lc), (ma, mc), (va, vc)):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), tag
+        done += 1
+    assert done >= 6, done
+
+
 def test_split_labels_features_fuzz_equal_oracle(dev):
     rng = np.random.default_rng(5)
     for it in range(20 * SOAK):
