@@ -75,7 +75,8 @@ static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, b
     // (LBDRNdataset.py:126-128) -- 96 MFMA steps instead of 100 at the headline shape.  LBDRN_EVAL_NOPAIR=1: A/B
     static const bool nopair = getenv("LBDRN_EVAL_NOPAIR") != nullptr;
     const int side = 2 * g.D + 1;
-    q.pair = fast && !nopair && g.use_colors && g.D >= 1 && g.D <= 3 && (g.C % 2) == 0 && q.ncolor == g.C * side * side;
+    q.pair = fast && !nopair && q.NT <= 2 && g.use_colors && g.D >= 1 && g.D <= 3 && (g.C % 2) == 0 && q.ncolor == g.C * side * side;
+    // (NT = 4, bc = 128: the pair's 24 operands on top of 128 accumulator / activation registers would spill at two waves per SIMD)
     q.RS = side * side - ((g.relative && g.D > 0) ? 1 : 0);
     if (q.pair) q.S0 = g.P + (g.C / 2) * q.RS;
     const int half = net.bc / 2;
