@@ -642,7 +642,7 @@ static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const
                       double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
 {
     WApplyArgs A;
-    if (!make_wapply_plan(g, net, &A.p)) {
+    if (!make_wapply_plan(g, net, &A.p, mode == MODE_EVAL_FAST)) {
         set_error("shape not supported by the MFMA apply kernels");
         return LBDRN_E_UNSUPPORTED;
     }
@@ -652,7 +652,7 @@ static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const
     }
     float* packed = (float*)ws;
     double* partial = (double*)((char*)ws + align_up((size_t)A.p.pack_floats * 4, 256));
-    k_pack_apply_wide<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, packed);
+    k_pack_apply_wide<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, 2 * g.P, packed);
     LBDRN_LAUNCH_CHECK();
     A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
     A.partial = partial;
