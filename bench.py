@@ -284,7 +284,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
         if kt.get("train_avg_us"):
             r_us = float(kt["train_avg_us"]) + float(kt.get("dw_avg_us") or 0.0)   # (bc >= 128: both training launches)
             r_ach = per_launch * step * B / (r_us * 1e-6) / 1e12
-            out.update({"rocprof_kernel_us": r_us, "rocprof_kernel_min_us": kt.get("train_min_us"),
+            out.update({"rocprof_kernel_us": round(r_us, 2), "rocprof_kernel_min_us": kt.get("train_min_us"),
                         "rocprof_source": kt.get("source"), "frac_rocprof": round(r_ach / peak, 4),
                         "frac": round(min(ach, r_ach) / peak, 4)})
         for extra in ("timeline", "stamps"):   # in-kernel evidence (s_memrealtime builds), committed as data
@@ -409,7 +409,8 @@ def side_leg(codec, ops, tiles, a, path, label, **over):
     px = b.height * b.width
     tile_flop = tile_flops(b, ops, fit, path)
     roof = roofline_probe(codec, ops, fit, img_d, b, path, with_single=False)
-    keep = ("kernel", "fits_per_launch", "kernel_us", "marginal_us", "reduce_adam_us", "unaccounted_us", "train_step_pair_us",
+    keep = ("kernel", "fits_per_launch", "kernel_us", "forward_backward_us", "weight_gradient_us", "marginal_us", "reduce_adam_us",
+            "unaccounted_us", "train_step_pair_us",
             "flop_per_launch", "achieved", "frac", "frac_live", "frac_rocprof", "rocprof_kernel_us", "rocprof_source",
             "frac_of_occupied_cus", "apply_pass_ms", "apply_frac", "traffic", "mfma_busy_frac", "mfma_busy_frac_occupied_simds")
     out = {"workload": label, "steps": b.steps, "warmup": b.warmup, "tiles_in_flight": min(b.in_flight, b.steps),
