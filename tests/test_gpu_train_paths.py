@@ -658,6 +658,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] > 0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     assert r["kernel_us"] > 0 and r["reduce_adam_us"] > 0 and "unaccounted_us" in r
+    # round 4: the kernel's own duration and the marginal (doubling-probe) figure side by side; the timed launch sequence
+    # checked against the same tile fitted alone; the legs of the other configurations only at the headline size
+    assert r["marginal_us"] > 0 and abs(r["frac_live"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] <= r["frac_live"] + 1e-9
+    assert d["timed_equals_lone"] is True and "other_configs" not in d
     assert d["repeats"] == 3 and len(d["ms_per_step_all_repeats"]) == 3 and d["ranks_seen"] == 1 and len(d["rank_elapsed_ms"]) == 1
     assert min(d["ms_per_step_all_repeats"]) <= d["ms_per_step"] <= max(d["ms_per_step_all_repeats"])
     c = d["cpu_baseline"]
