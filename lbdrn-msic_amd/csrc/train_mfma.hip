@@ -317,7 +317,11 @@ __global__ void __launch_bounds__(256)
 // leave in row-major order as 16-byte stores (the per-element kernel above spends its time in 64-bit index divisions
 // and scattered uint16 gathers: 0.7 TB/s; this one: 1.8 ms for the 3.49 GB of a 2048^2 x 8 tile, 2.9 ms before the
 // table and the wide stores).
-constexpr int BR_TW = 32;
+#ifndef LBDRN_BR_TW
+#define LBDRN_BR_TW 32
+#endif
+constexpr int BR_TW = LBDRN_BR_TW;   // pixels per block.  A/B (round 4, alone on the device): 32: 1.80 ms, 64: 1.61, 128: 1.66 -- but at 64 the
+                                     // launch needs 16 KB of LDS and no longer fits beside the training workgroups of other fits (13.5 KB free)
 __global__ void __launch_bounds__(256)
     k_build_rows_tiled(lbdrn_geom g, int F, int RP, int LQs, FeatMap fm, const uint16_t* __restrict__ msb,
                        const uint16_t* __restrict__ img, float* __restrict__ rows)
