@@ -12,15 +12,15 @@
 // whatever sat at position i' before step i', where i' is the latest step < i with j_i' = p -- a
 // chain that walks to ever earlier steps (one hop on average).  So:
 //   1. one wave runs the MT19937 recurrence and emits the raw words; the targets j_i are made of them by
-//      4 M threads;  2. the steps are bucketed by target (count, exclusive scan, scatter);
-//   3. every position chases its chain, independently (k_links prepares one array for the first hop and one for the
-//      later ones from the buckets).
-// Bucket order is irrelevant (each hop takes the maximum step below a bound), so the atomics used to
-// fill the buckets do not affect the result.  tests/test_gpu_randperm.py checks equality with
-// torch.randperm for many (seed, n).
+//      4 M threads;  2. the steps that share a target are linked into a list per target (one atomic exchange per step:
+//      round 4 -- rounds 2-3 counted, scanned and scattered them into buckets: six random accesses per step, now four,
+//      and no scan; the pipeline costs a tile 7 ms of the chip with four fits in flight, scripts/perm_cost_probe.py);
+//   3. every position walks its own (short) list once and leaves, for every step in it, the latest earlier step with the
+//      same target (the first hop of that step's chain) and, for itself, the latest step below it (every later hop);
+//   4. every position chases its chain, independently.
+// List order is irrelevant (each hop takes the maximum step below a bound), so the order in which the atomics
+// land does not affect the result.  tests/test_gpu_randperm.py checks equality with torch.randperm for many (seed, n).
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "common.hpp"
 
@@ -112,52 +112,60 @@ __global__ void __launch_bounds__(64) k_mt19937_raw(SeedList seeds, uint32_t n, 
 
 __device__ __forceinline__ uint32_t mt_target(uint32_t raw, uint32_t i, uint32_t n) { return i + mt_temper(raw) % (n - i); }
 
-// j[i] = i + mt19937_output(i) % (n - i) for i < n-1, in place over the raw words; and the bucket sizes
-__global__ void __launch_bounds__(256) k_count_targets(uint32_t* __restrict__ j, uint32_t steps, uint32_t n, uint32_t* __restrict__ cnt)
+// j[i] = i + mt19937_output(i) % (n - i) for i < n-1, in place over the raw words; step i is pushed onto the list of
+// its target: head[t] = i, next[i] = the previous head (-1: end).  ONE random access per step (the exchange); next[] is
+// written where the step sits.
+__global__ void __launch_bounds__(256)
+    k_link_targets(uint32_t* __restrict__ j, uint32_t steps, uint32_t n, int32_t* __restrict__ head, int32_t* __restrict__ next)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < steps) {
         const uint32_t t = mt_target(j[i], i, n);
         j[i] = t;
-        atomicAdd(&cnt[t], 1u);
+        next[i] = atomicExch(&head[t], (int32_t)i);
     }
 }
 
+// The chains: position p walks its own list once (the steps that target it: one on average, ~ln n at the far end) and
+// leaves, for every step x in it, the latest earlier step with the same target (pred[x]: the first hop of x's chain),
+// and for itself the latest step below p that targets it (last[p]: every later hop -- the steps that target p are <= p).
+// last overwrites head in place (a thread reads only its own head; the walks read next[] alone).
+constexpr int LINK_REG = 8;   // list lengths handled in registers; longer lists (a vanishing share) walk again per element
 __global__ void __launch_bounds__(256)
-    k_fill_buckets(const uint32_t* __restrict__ j, uint32_t steps, const uint32_t* __restrict__ off,
-                   uint32_t* __restrict__ cursor, uint32_t* __restrict__ entries)
+    k_links(uint32_t n, int32_t* head_last, const int32_t* __restrict__ next, int32_t* __restrict__ pred)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < steps) {
-        uint32_t p = j[i];
-        entries[off[p] + atomicAdd(&cursor[p], 1u)] = i;
-    }
-}
-
-// The chains, two random accesses per index instead of nine: position p walks its own (small, contiguous) bucket once
-// and leaves, for every step x in it, the latest earlier step with the same target (pred[x]: the first hop of x's
-// chain), and for itself the latest step below p that targets it (last[p]: every later hop -- the steps that target
-// p are <= p).  last overwrites cnt in place (each thread reads only its own count), pred takes the dead cursor array.
-__global__ void __launch_bounds__(256)
-    k_links(uint32_t n, const uint32_t* __restrict__ off, uint32_t* cnt_last, const uint32_t* __restrict__ entries,
-            int32_t* __restrict__ pred)
-{
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
-    const uint32_t b = off[p], e = b + cnt_last[p];
+    const int32_t h = head_last[p];
+    int32_t e[LINK_REG];
+    int len = 0;
     int32_t last = -1;
-    for (uint32_t k = b; k < e; ++k) {
-        const uint32_t x = entries[k];
-        int32_t best = -1;
-        for (uint32_t m = b; m < e; ++m) {
-            const uint32_t y = entries[m];
-            if (y < x && (int32_t)y > best) best = (int32_t)y;
-        }
-        pred[x] = best;
-        if (x < p && (int32_t)x > last) last = (int32_t)x;
+    for (int32_t x = h; x >= 0; x = next[x]) {
+        if (len < LINK_REG) e[len] = x;
+        ++len;
+        if ((uint32_t)x < p && x > last) last = x;
     }
-    cnt_last[p] = (uint32_t)last;
-    if (p == n - 1) pred[p] = last;   // the last position is nobody's step: its chain starts at its own bucket
+    if (len <= LINK_REG) {
+#pragma unroll
+        for (int a = 0; a < LINK_REG; ++a) {
+            if (a < len) {
+                int32_t best = -1;
+#pragma unroll
+                for (int b = 0; b < LINK_REG; ++b)
+                    if (b < len && e[b] < e[a] && e[b] > best) best = e[b];
+                pred[e[a]] = best;
+            }
+        }
+    } else {
+        for (int32_t x = h; x >= 0; x = next[x]) {
+            int32_t best = -1;
+            for (int32_t y = h; y >= 0; y = next[y])
+                if (y < x && y > best) best = y;
+            pred[x] = best;
+        }
+    }
+    head_last[p] = last;
+    if (p == n - 1) pred[p] = last;   // the last position is nobody's step: its chain starts at its own list
 }
 
 __global__ void __launch_bounds__(256)
@@ -176,27 +184,18 @@ __global__ void __launch_bounds__(256)
 }
 
 struct PermWs {
-    uint32_t *j, *cnt, *off, *cursor, *entries;
-    void* scan_tmp;
-    size_t scan_bytes, arr, total;
+    uint32_t *j, *cnt, *off, *cursor;
+    size_t arr, total;
 };
 
 static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
 {
-    size_t scan_bytes = 0;
-    uint32_t* nul = nullptr;
-    if (rocprim::exclusive_scan(nullptr, scan_bytes, nul, nul, 0u, (size_t)std::max<int64_t>(n, 1),
-                                rocprim::plus<uint32_t>()) != hipSuccess)
-        return LBDRN_E_DEVICE;
     const size_t arr = align_up((size_t)std::max<int64_t>(n, 1) * sizeof(uint32_t), 256);
     char* p = (char*)ws;
     w->j = (uint32_t*)p; p += arr * count;     // one target array per permutation
-    w->cnt = (uint32_t*)p; p += arr;
-    w->cursor = (uint32_t*)p; p += arr;         // cnt and cursor adjacent: one memset
-    w->off = (uint32_t*)p; p += arr;
-    w->entries = (uint32_t*)p; p += arr;
-    w->scan_tmp = p; p += align_up(scan_bytes, 256);
-    w->scan_bytes = scan_bytes;
+    w->cnt = (uint32_t*)p; p += arr;            // head[], then last[]
+    w->cursor = (uint32_t*)p; p += arr;         // pred[]
+    w->off = (uint32_t*)p; p += arr;            // next[]
     w->arr = arr;
     w->total = (size_t)(p - (char*)ws);
     return 0;
@@ -232,18 +231,12 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
     LBDRN_LAUNCH_CHECK();
     for (int c = 0; c < count; ++c) {
         uint32_t* j = w.j + (size_t)c * (w.arr / sizeof(uint32_t));
-        LBDRN_HIP_TRY(hipMemsetAsync(w.cnt, 0, 2 * w.arr, s));
+        LBDRN_HIP_TRY(hipMemsetAsync(w.cnt, 0xFF, w.arr, s));   // head[] = -1
         if (steps) {
-            k_count_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, un, w.cnt);
+            k_link_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, un, (int32_t*)w.cnt, (int32_t*)w.off);
             LBDRN_LAUNCH_CHECK();
         }
-        LBDRN_HIP_TRY(rocprim::exclusive_scan(w.scan_tmp, w.scan_bytes, w.cnt, w.off, 0u, (size_t)n,
-                                              rocprim::plus<uint32_t>(), s));
-        if (steps) {
-            k_fill_buckets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, w.off, w.cursor, w.entries);
-            LBDRN_LAUNCH_CHECK();
-        }
-        k_links<<<(un + 255) / 256, 256, 0, s>>>(un, w.off, w.cnt, w.entries, (int32_t*)w.cursor);
+        k_links<<<(un + 255) / 256, 256, 0, s>>>(un, (int32_t*)w.cnt, (const int32_t*)w.off, (int32_t*)w.cursor);
         LBDRN_LAUNCH_CHECK();
         k_chase<<<(un + 255) / 256, 256, 0, s>>>(j, un, (const int32_t*)w.cursor, (const int32_t*)w.cnt, out + (size_t)c * n);
         LBDRN_LAUNCH_CHECK();
