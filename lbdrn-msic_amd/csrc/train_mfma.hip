@@ -360,6 +360,18 @@ __global__ void __launch_bounds__(256)
     __syncthreads();   // window and offset tables are in LDS
     const bool rel = g.relative && g.D > 0;
     int2* ptab = reinterpret_cast<int2*>(cto + ncolor);   // [RP]; 8-byte aligned as it stands: C side SW (SW = 32 + 2 D) and 2 ncolor are both even
+    // the block's labels, staged like the window (round 4): the store loop below used to fetch each label with a 2-byte
+    // global load of its own -- consecutive threads walk the positions of ONE pixel, so eight planes per pixel, no two
+    // loads in a line -- in the middle of the stores
+    float* labs = reinterpret_cast<float*>(ptab + RP);     // [C][BR_TW]
+    {
+        const int lmask = (1 << g.K) - 1;
+        const float lmaskf = (float)lmask;
+        for (int e = tid; e < g.C * BR_TW; e += 256) {
+            const int c = e / BR_TW, px = e - c * BR_TW;
+            labs[e] = (float)((int)img[(int64_t)c * HW + (int64_t)y * g.W + min(x0 + px, g.W - 1)] & lmask) / lmaskf;
+        }
+    }
     for (int pos = tid; pos < RP; pos += 256) {
         const int f = row_source(pos, LQs, F, g.C, fm);
         int2 t = make_int2(-1, 0);
@@ -371,10 +383,7 @@ __global__ void __launch_bounds__(256)
         ptab[pos] = t;
     }
     __syncthreads();
-    const int mask = (1 << g.K) - 1;
-    const float maskf = (float)mask;
     float* out = rows + ((int64_t)y * g.W + x0) * RP;
-    const int64_t pix0 = (int64_t)y * g.W + x0;
     auto value = [&](int pos, int pix) -> float {
         const int2 t = ptab[pos];
         if (t.x >= 0) {
@@ -384,7 +393,7 @@ __global__ void __launch_bounds__(256)
         if (t.x == -1) return 0.0f;
         if (t.x == -2) return g.rowtab[(int64_t)y * g.P + t.y];
         if (t.x == -3) return g.coltab[(int64_t)(x0 + pix) * g.P + t.y];
-        return (float)((int)img[(int64_t)t.y * HW + pix0 + pix] & mask) / maskf;
+        return labs[t.y * BR_TW + pix];
     };
     if ((RP & 3) == 0) {
         // four consecutive positions of one pixel per thread and trip: one 16-byte store (rows are 16-byte aligned: RP % 4 == 0)
@@ -1218,7 +1227,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     LBDRN_REQUIRE((total + 255) / 256 < ((int64_t)1 << 31), "image too large for one launch");
     const int side = 2 * g.D + 1;
     const size_t ncol = (size_t)std::max(net.F - 2 * g.P, 0);
-    const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + 2 * (size_t)p.RP) * 4;   // window + offsets + position table
+    const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + 2 * (size_t)p.RP + (size_t)g.C * BR_TW) * 4;   // window + offsets + position table + labels
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
         k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
