@@ -20,6 +20,7 @@
 //   4. every position chases its chain, independently.
 // List order is irrelevant (each hop takes the maximum step below a bound), so the order in which the atomics
 // land does not affect the result.  tests/test_gpu_randperm.py checks equality with torch.randperm for many (seed, n).
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -168,6 +169,163 @@ __global__ void __launch_bounds__(256)
     if (p == n - 1) pred[p] = last;   // the last position is nobody's step: its chain starts at its own list
 }
 
+// ---- the partitioned path (n <= PART_MAX_N; round 4).  The list building above costs one memory-side atomic and two more
+// random accesses per step, and with fits in flight every one of them competes with the training launches' gathers
+// (the pipeline cost a tile 7 ms of 63).  Here the steps are first routed to the partition of 2048 POSITIONS their target
+// falls into -- a counting pass, a scan of the (partition, workgroup) counts and a scatter of (step, target) pairs, all
+// coalesced or in 64-byte pieces --, and one workgroup per partition then builds that partition's lists with LDS atomics
+// (its heads are 8 KB of LDS), walking them through the partition's own pairs (L2-resident).  What is left of the
+// random traffic is one 4-byte write per step (pred[step]) and the chase.
+// Partition = 2048 positions: the far end of the array is dense with targets (position p is hit ln(n / (n - p)) times on
+// average: 8.6 per position in the last partition against 1 overall), and a partition's workgroup walks its lists one
+// dependent load at a time -- 8192-position partitions left one workgroup with 59 k pairs and the launch at 0.7 ms.
+constexpr int PART_SHIFT = 11, PART_SIZE = 1 << PART_SHIFT, PART_MAX = 2048;
+constexpr int64_t PART_MAX_N = (int64_t)PART_MAX << PART_SHIFT;   // 4,194,304: the 2048^2 tile
+constexpr int PART_CHUNK = 16384;   // steps per workgroup of the counting / scattering passes: eight pairs = 64 bytes per partition on average
+
+// targets (in place over the raw words) + this workgroup's count per partition: histT[partition][workgroup]
+__global__ void __launch_bounds__(256)
+    k_part_count(uint32_t* __restrict__ j, uint32_t steps, uint32_t n, int npart, int nwg, uint32_t* __restrict__ histT)
+{
+    __shared__ uint32_t hist[PART_MAX];
+    for (int k = threadIdx.x; k < PART_MAX; k += 256) hist[k] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * PART_CHUNK;
+#pragma unroll 4
+    for (int u = 0; u < PART_CHUNK / 256; ++u) {
+        const uint32_t i = base + u * 256 + threadIdx.x;
+        if (i < steps) {
+            const uint32_t t = mt_target(j[i], i, n);
+            j[i] = t;
+            atomicAdd(&hist[t >> PART_SHIFT], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < npart; k += 256) histT[(size_t)k * nwg + blockIdx.x] = hist[k];
+}
+
+// exclusive scan of every partition's row of workgroup counts (in place) and the row totals; then the totals themselves:
+// a pair of (partition p, workgroup w) starts at part_start[p] + histT[p][w]
+__global__ void __launch_bounds__(1024) k_part_scan_rows(uint32_t* __restrict__ histT, int nwg, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t sums[1024];
+    const int tid = threadIdx.x;
+    uint32_t* row = histT + (size_t)blockIdx.x * nwg;
+    uint32_t run = 0;   // (nwg <= 1024 at the sizes this path takes; the loop keeps it general)
+    for (int base = 0; base < nwg; base += 1024) {
+        const int k = base + tid;
+        const uint32_t c = k < nwg ? row[k] : 0u;
+        sums[tid] = c;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const uint32_t v = tid >= d ? sums[tid - d] : 0u;
+            __syncthreads();
+            sums[tid] += v;
+            __syncthreads();
+        }
+        if (k < nwg) row[k] = run + sums[tid] - c;
+        run += sums[1023];
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = run;   // (second use, one row = the partitions' totals: totals = &part_start[npart])
+}
+// (step, target) pairs in partition order
+__global__ void __launch_bounds__(256)
+    k_part_scatter(const uint32_t* __restrict__ j, uint32_t steps, int npart, int nwg, const uint32_t* __restrict__ offs,
+                   const uint32_t* __restrict__ part_start, uint2* __restrict__ pairs)
+{
+    __shared__ uint32_t cursor[PART_MAX];
+    for (int k = threadIdx.x; k < npart; k += 256) cursor[k] = part_start[k] + offs[(size_t)k * nwg + blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * PART_CHUNK;
+#pragma unroll 4
+    for (int u = 0; u < PART_CHUNK / 256; ++u) {
+        const uint32_t i = base + u * 256 + threadIdx.x;
+        if (i < steps) {
+            const uint32_t t = j[i];
+            pairs[atomicAdd(&cursor[t >> PART_SHIFT], 1u)] = make_uint2(i, t);
+        }
+    }
+}
+
+// one workgroup per partition: lists of its positions out of its pairs (heads in LDS; a link = (previous head, step) per
+// pair index, so that a walk is one 8-byte load per entry), then for every position the predecessors of its list's steps
+// (pred[step]) and the latest step below it (last[position]).  Lists up to LINK_REG entries are ordered in registers,
+// longer ones (the far end of the array: ~ln n entries) in a per-thread strip of LDS.
+constexpr int LINK_LDS = 24;   // entries of a thread's LDS strip; longer lists (a handful per permutation) re-walk
+constexpr int LINK_THREADS = 512;   // the walks are chains of dependent loads: sixteen waves per CU keep more of them in flight
+                                    // (256 threads: 204 us per launch, 512: 141; 1024 with strips of 12 entries: 206)
+__global__ void __launch_bounds__(LINK_THREADS)
+    k_part_links(uint32_t n, const uint32_t* __restrict__ part_start, const uint2* __restrict__ pairs, int2* __restrict__ links,
+                 int32_t* __restrict__ pred, int32_t* __restrict__ last)
+{
+    __shared__ int32_t head[PART_SIZE];
+    __shared__ int32_t strip[LINK_THREADS][LINK_LDS + 1];   // (+1: the strips of neighbouring threads start in different banks)
+    const uint32_t part = gridDim.x - 1 - blockIdx.x;   // the dense partitions (the far end of the array) first: they take ten times as long
+    const uint32_t base = part << PART_SHIFT;
+    const uint32_t k0 = part_start[part], k1 = part_start[part + 1];
+    for (int k = threadIdx.x; k < PART_SIZE; k += LINK_THREADS) head[k] = -1;
+    __syncthreads();
+    for (uint32_t k = k0 + threadIdx.x; k < k1; k += LINK_THREADS) {
+        const uint2 pr = pairs[k];
+        links[k] = make_int2(atomicExch(&head[pr.y - base], (int32_t)k), (int32_t)pr.x);
+    }
+    __threadfence_block();
+    __syncthreads();
+    int32_t* mine = strip[threadIdx.x];
+    for (uint32_t lp = threadIdx.x; lp < PART_SIZE; lp += LINK_THREADS) {
+        const uint32_t p = base + lp;
+        if (p >= n) break;
+        const int32_t h = head[lp];
+        int32_t e[LINK_REG];
+        int len = 0;
+        int32_t lastv = -1;
+        for (int32_t k = h; k >= 0;) {
+            const int2 l = links[k];
+            const int32_t x = l.y;
+            if (len < LINK_REG) e[len] = x;
+            if (len < LINK_LDS) mine[len] = x;
+            ++len;
+            if ((uint32_t)x < p && x > lastv) lastv = x;
+            k = l.x;
+        }
+        if (len <= LINK_REG) {
+#pragma unroll
+            for (int a = 0; a < LINK_REG; ++a) {
+                if (a < len) {
+                    int32_t best = -1;
+#pragma unroll
+                    for (int b = 0; b < LINK_REG; ++b)
+                        if (b < len && e[b] < e[a] && e[b] > best) best = e[b];
+                    pred[e[a]] = best;
+                }
+            }
+        } else if (len <= LINK_LDS) {
+            for (int a = 0; a < len; ++a) {
+                const int32_t x = mine[a];
+                int32_t best = -1;
+                for (int b = 0; b < len; ++b) {
+                    const int32_t y = mine[b];
+                    if (y < x && y > best) best = y;
+                }
+                pred[x] = best;
+            }
+        } else {
+            for (int32_t k = h; k >= 0; k = links[k].x) {
+                const int32_t x = links[k].y;
+                int32_t best = -1;
+                for (int32_t m = h; m >= 0; m = links[m].x) {
+                    const int32_t y = links[m].y;
+                    if (y < x && y > best) best = y;
+                }
+                pred[x] = best;
+            }
+        }
+        last[p] = lastv;
+        if (p == n - 1) pred[p] = lastv;   // the last position is nobody's step: its chain starts at its own list
+    }
+}
+
 __global__ void __launch_bounds__(256)
     k_chase(const uint32_t* __restrict__ j, uint32_t n, const int32_t* __restrict__ pred,
             const int32_t* __restrict__ last, int64_t* __restrict__ out)
@@ -185,8 +343,16 @@ __global__ void __launch_bounds__(256)
 
 struct PermWs {
     uint32_t *j, *cnt, *off, *cursor;
+    uint2* pairs;            // partitioned path: (step, target) in partition order
+    int2* links;             // (previous head of the target's list, step) per pair
+    uint32_t *histT, *part_start;
     size_t arr, total;
 };
+static bool perm_partitioned(int64_t n)
+{
+    static const bool off = getenv("LBDRN_RANDPERM_ATOMIC") != nullptr;   // A/B: the memory-side atomic path for every n
+    return !off && n > 16 * PART_SIZE && n <= PART_MAX_N;
+}
 
 static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
 {
@@ -196,6 +362,14 @@ static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
     w->cnt = (uint32_t*)p; p += arr;            // head[], then last[]
     w->cursor = (uint32_t*)p; p += arr;         // pred[]
     w->off = (uint32_t*)p; p += arr;            // next[]
+    w->pairs = nullptr; w->links = nullptr; w->histT = nullptr; w->part_start = nullptr;
+    if (perm_partitioned(n)) {
+        const size_t nwg = (size_t)((n + PART_CHUNK - 1) / PART_CHUNK), npart = (size_t)((n + PART_SIZE - 1) >> PART_SHIFT);
+        w->pairs = (uint2*)p; p += align_up((size_t)n * sizeof(uint2), 256);
+        w->links = (int2*)p; p += align_up((size_t)n * sizeof(int2), 256);
+        w->histT = (uint32_t*)p; p += align_up(nwg * npart * sizeof(uint32_t), 256);
+        w->part_start = (uint32_t*)p; p += align_up((npart + 1) * sizeof(uint32_t), 256);
+    }
     w->arr = arr;
     w->total = (size_t)(p - (char*)ws);
     return 0;
@@ -231,6 +405,22 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
     LBDRN_LAUNCH_CHECK();
     for (int c = 0; c < count; ++c) {
         uint32_t* j = w.j + (size_t)c * (w.arr / sizeof(uint32_t));
+        if (w.pairs && steps) {   // the partitioned path
+            const int nwg = (int)((steps + PART_CHUNK - 1) / PART_CHUNK), npart = (int)((un + PART_SIZE - 1) >> PART_SHIFT);
+            k_part_count<<<nwg, 256, 0, s>>>(j, steps, un, npart, nwg, w.histT);
+            LBDRN_LAUNCH_CHECK();
+            k_part_scan_rows<<<npart, 1024, 0, s>>>(w.histT, nwg, w.part_start);            // row totals -> part_start[partition]
+            LBDRN_LAUNCH_CHECK();
+            k_part_scan_rows<<<1, 1024, 0, s>>>(w.part_start, npart, w.part_start + npart);   // their exclusive scan in place, the grand total behind
+            LBDRN_LAUNCH_CHECK();
+            k_part_scatter<<<nwg, 256, 0, s>>>(j, steps, npart, nwg, w.histT, w.part_start, w.pairs);
+            LBDRN_LAUNCH_CHECK();
+            k_part_links<<<npart, LINK_THREADS, 0, s>>>(un, w.part_start, w.pairs, w.links, (int32_t*)w.cursor, (int32_t*)w.cnt);
+            LBDRN_LAUNCH_CHECK();
+            k_chase<<<(un + 255) / 256, 256, 0, s>>>(j, un, (const int32_t*)w.cursor, (const int32_t*)w.cnt, out + (size_t)c * n);
+            LBDRN_LAUNCH_CHECK();
+            continue;
+        }
         LBDRN_HIP_TRY(hipMemsetAsync(w.cnt, 0xFF, w.arr, s));   // head[] = -1
         if (steps) {
             k_link_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, un, (int32_t*)w.cnt, (int32_t*)w.off);
