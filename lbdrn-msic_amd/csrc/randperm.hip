@@ -183,10 +183,22 @@ constexpr int PART_SHIFT = 11, PART_SIZE = 1 << PART_SHIFT, PART_MAX = 2048;
 constexpr int64_t PART_MAX_N = (int64_t)PART_MAX << PART_SHIFT;   // 4,194,304: the 2048^2 tile
 constexpr int PART_CHUNK = 16384;   // steps per workgroup of the counting / scattering passes: eight pairs = 64 bytes per partition on average
 
+// The permutations of one call go through every launch TOGETHER (blockIdx.y = permutation, each with its own arrays at
+// a fixed stride): a launch boundary is an L2 write-back + invalidate across the XCDs, felt by the training launches of
+// the fits in flight -- six launches per batch of nine permutations instead of fifty-four.
+struct PartArrays {
+    uint32_t *j, *histT, *part_start;   // per permutation: + c * stride
+    uint2* pairs;
+    int2* links;
+    int32_t *pred, *last;
+    size_t sj, shist, sstart, sn;       // strides in elements: targets, histT, part_start, everything of n entries
+};
+
 // targets (in place over the raw words) + this workgroup's count per partition: histT[partition][workgroup]
-__global__ void __launch_bounds__(256)
-    k_part_count(uint32_t* __restrict__ j, uint32_t steps, uint32_t n, int npart, int nwg, uint32_t* __restrict__ histT)
+__global__ void __launch_bounds__(256) k_part_count(PartArrays A, uint32_t steps, uint32_t n, int npart, int nwg)
 {
+    uint32_t* __restrict__ j = A.j + blockIdx.y * A.sj;
+    uint32_t* __restrict__ histT = A.histT + blockIdx.y * A.shist;
     __shared__ uint32_t hist[PART_MAX];
     for (int k = threadIdx.x; k < PART_MAX; k += 256) hist[k] = 0;
     __syncthreads();
@@ -206,10 +218,12 @@ __global__ void __launch_bounds__(256)
 
 // exclusive scan of every partition's row of workgroup counts (in place) and the row totals; then the totals themselves:
 // a pair of (partition p, workgroup w) starts at part_start[p] + histT[p][w]
-__global__ void __launch_bounds__(1024) k_part_scan_rows(uint32_t* __restrict__ histT, int nwg, uint32_t* __restrict__ totals)
+__global__ void __launch_bounds__(1024) k_part_scan_rows(uint32_t* __restrict__ histT0, size_t sh, int nwg, uint32_t* __restrict__ totals0, size_t st)
 {
     __shared__ uint32_t sums[1024];
     const int tid = threadIdx.x;
+    uint32_t* __restrict__ histT = histT0 + blockIdx.y * sh;
+    uint32_t* __restrict__ totals = totals0 + blockIdx.y * st;
     uint32_t* row = histT + (size_t)blockIdx.x * nwg;
     uint32_t run = 0;   // (nwg <= 1024 at the sizes this path takes; the loop keeps it general)
     for (int base = 0; base < nwg; base += 1024) {
@@ -231,9 +245,12 @@ __global__ void __launch_bounds__(1024) k_part_scan_rows(uint32_t* __restrict__ 
 }
 // (step, target) pairs in partition order
 __global__ void __launch_bounds__(256)
-    k_part_scatter(const uint32_t* __restrict__ j, uint32_t steps, int npart, int nwg, const uint32_t* __restrict__ offs,
-                   const uint32_t* __restrict__ part_start, uint2* __restrict__ pairs)
+    k_part_scatter(PartArrays A, uint32_t steps, int npart, int nwg)
 {
+    const uint32_t* __restrict__ j = A.j + blockIdx.y * A.sj;
+    const uint32_t* __restrict__ offs = A.histT + blockIdx.y * A.shist;
+    const uint32_t* __restrict__ part_start = A.part_start + blockIdx.y * A.sstart;
+    uint2* __restrict__ pairs = A.pairs + blockIdx.y * A.sn;
     __shared__ uint32_t cursor[PART_MAX];
     for (int k = threadIdx.x; k < npart; k += 256) cursor[k] = part_start[k] + offs[(size_t)k * nwg + blockIdx.x];
     __syncthreads();
@@ -256,9 +273,13 @@ constexpr int LINK_LDS = 24;   // entries of a thread's LDS strip; longer lists 
 constexpr int LINK_THREADS = 512;   // the walks are chains of dependent loads: sixteen waves per CU keep more of them in flight
                                     // (256 threads: 204 us per launch, 512: 141; 1024 with strips of 12 entries: 206)
 __global__ void __launch_bounds__(LINK_THREADS)
-    k_part_links(uint32_t n, const uint32_t* __restrict__ part_start, const uint2* __restrict__ pairs, int2* __restrict__ links,
-                 int32_t* __restrict__ pred, int32_t* __restrict__ last)
+    k_part_links(PartArrays A, uint32_t n)
 {
+    const uint32_t* __restrict__ part_start = A.part_start + blockIdx.y * A.sstart;
+    const uint2* __restrict__ pairs = A.pairs + blockIdx.y * A.sn;
+    int2* __restrict__ links = A.links + blockIdx.y * A.sn;
+    int32_t* __restrict__ pred = A.pred + blockIdx.y * A.sn;
+    int32_t* __restrict__ last = A.last + blockIdx.y * A.sn;
     __shared__ int32_t head[PART_SIZE];
     __shared__ int32_t strip[LINK_THREADS][LINK_LDS + 1];   // (+1: the strips of neighbouring threads start in different banks)
     const uint32_t part = gridDim.x - 1 - blockIdx.x;   // the dense partitions (the far end of the array) first: they take ten times as long
@@ -297,7 +318,7 @@ __global__ void __launch_bounds__(LINK_THREADS)
 #pragma unroll
                     for (int b = 0; b < LINK_REG; ++b)
                         if (b < len && e[b] < e[a] && e[b] > best) best = e[b];
-                    pred[e[a]] = best;
+                    if (best >= 0) pred[e[a]] = best;   // (pred[] starts at -1: two steps in three have no earlier step with their target)
                 }
             }
         } else if (len <= LINK_LDS) {
@@ -308,7 +329,7 @@ __global__ void __launch_bounds__(LINK_THREADS)
                     const int32_t y = mine[b];
                     if (y < x && y > best) best = y;
                 }
-                pred[x] = best;
+                if (best >= 0) pred[x] = best;
             }
         } else {
             for (int32_t k = h; k >= 0; k = links[k].x) {
@@ -318,7 +339,7 @@ __global__ void __launch_bounds__(LINK_THREADS)
                     const int32_t y = links[m].y;
                     if (y < x && y > best) best = y;
                 }
-                pred[x] = best;
+                if (best >= 0) pred[x] = best;
             }
         }
         last[p] = lastv;
@@ -341,11 +362,30 @@ __global__ void __launch_bounds__(256)
     out[i] = p;
 }
 
+// the chase of every permutation of the call (the partitioned path's arrays)
+__global__ void __launch_bounds__(256) k_chase_batch(PartArrays A, uint32_t n, int64_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* __restrict__ j = A.j + blockIdx.y * A.sj;
+    const int32_t* __restrict__ pred = A.pred + blockIdx.y * A.sn;
+    const int32_t* __restrict__ last = A.last + blockIdx.y * A.sn;
+    int32_t s = pred[i];
+    uint32_t p = j[i];
+    while (s >= 0) {
+        p = (uint32_t)s;
+        s = last[p];
+    }
+    out[(size_t)blockIdx.y * n + i] = p;
+}
+
 struct PermWs {
     uint32_t *j, *cnt, *off, *cursor;
     uint2* pairs;            // partitioned path: (step, target) in partition order
     int2* links;             // (previous head of the target's list, step) per pair
+    int32_t *pred, *last;
     uint32_t *histT, *part_start;
+    size_t sn, shist, sstart;
     size_t arr, total;
 };
 static bool perm_partitioned(int64_t n)
@@ -362,13 +402,18 @@ static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
     w->cnt = (uint32_t*)p; p += arr;            // head[], then last[]
     w->cursor = (uint32_t*)p; p += arr;         // pred[]
     w->off = (uint32_t*)p; p += arr;            // next[]
-    w->pairs = nullptr; w->links = nullptr; w->histT = nullptr; w->part_start = nullptr;
-    if (perm_partitioned(n)) {
+    w->pairs = nullptr; w->links = nullptr; w->histT = nullptr; w->part_start = nullptr; w->pred = nullptr; w->last = nullptr;
+    if (perm_partitioned(n)) {   // every permutation of the call has its own arrays: they go through the launches together
         const size_t nwg = (size_t)((n + PART_CHUNK - 1) / PART_CHUNK), npart = (size_t)((n + PART_SIZE - 1) >> PART_SHIFT);
-        w->pairs = (uint2*)p; p += align_up((size_t)n * sizeof(uint2), 256);
-        w->links = (int2*)p; p += align_up((size_t)n * sizeof(int2), 256);
-        w->histT = (uint32_t*)p; p += align_up(nwg * npart * sizeof(uint32_t), 256);
-        w->part_start = (uint32_t*)p; p += align_up((npart + 1) * sizeof(uint32_t), 256);
+        w->sn = align_up((size_t)n * sizeof(uint2), 256) / sizeof(uint2);          // stride of the n-entry arrays, in entries
+        w->shist = align_up(nwg * npart * sizeof(uint32_t), 256) / sizeof(uint32_t);
+        w->sstart = align_up((npart + 1) * sizeof(uint32_t), 256) / sizeof(uint32_t);
+        w->pairs = (uint2*)p; p += w->sn * sizeof(uint2) * count;
+        w->links = (int2*)p; p += w->sn * sizeof(int2) * count;
+        w->pred = (int32_t*)p; p += w->sn * sizeof(int32_t) * count;
+        w->last = (int32_t*)p; p += w->sn * sizeof(int32_t) * count;
+        w->histT = (uint32_t*)p; p += w->shist * sizeof(uint32_t) * count;
+        w->part_start = (uint32_t*)p; p += w->sstart * sizeof(uint32_t) * count;
     }
     w->arr = arr;
     w->total = (size_t)(p - (char*)ws);
@@ -401,26 +446,36 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
     const uint32_t un = (uint32_t)n, steps = un - 1;
     SeedList sl;
     for (int c = 0; c < 32; ++c) sl.s[c] = c < count ? (uint32_t)(seeds[c] & 0xffffffffu) : 0u;
-    k_mt19937_raw<<<count, 64, 0, s>>>(sl, un, w.j, w.arr / sizeof(uint32_t));
-    LBDRN_LAUNCH_CHECK();
+    // timing experiments only (the permutations are then garbage; the training kernels clamp what they read):
+    // LBDRN_RANDPERM_DIAG bit 0 = no MT19937 launch, bit 1 = none of the launches behind it
+    static const int diag = getenv("LBDRN_RANDPERM_DIAG") ? atoi(getenv("LBDRN_RANDPERM_DIAG")) : 0;
+    if (!(diag & 1)) {
+        k_mt19937_raw<<<count, 64, 0, s>>>(sl, un, w.j, w.arr / sizeof(uint32_t));
+        LBDRN_LAUNCH_CHECK();
+    }
+    if (diag & 2) return 0;
+    if (w.pairs && steps) {   // the partitioned path: all permutations of the call per launch
+        const int nwg = (int)((steps + PART_CHUNK - 1) / PART_CHUNK), npart = (int)((un + PART_SIZE - 1) >> PART_SHIFT);
+        PartArrays A;
+        A.j = w.j; A.histT = w.histT; A.part_start = w.part_start; A.pairs = w.pairs; A.links = w.links; A.pred = w.pred; A.last = w.last;
+        A.sj = w.arr / sizeof(uint32_t); A.shist = w.shist; A.sstart = w.sstart; A.sn = w.sn;
+        LBDRN_HIP_TRY(hipMemsetAsync(w.pred, 0xFF, w.sn * sizeof(int32_t) * count, s));   // pred[] = -1: only the steps that HAVE a predecessor are written (at random)
+        k_part_count<<<dim3(nwg, count), 256, 0, s>>>(A, steps, un, npart, nwg);
+        LBDRN_LAUNCH_CHECK();
+        k_part_scan_rows<<<dim3(npart, count), 1024, 0, s>>>(w.histT, w.shist, nwg, w.part_start, w.sstart);   // row totals -> part_start[partition]
+        LBDRN_LAUNCH_CHECK();
+        k_part_scan_rows<<<dim3(1, count), 1024, 0, s>>>(w.part_start, w.sstart, npart, w.part_start + npart, w.sstart);   // their exclusive scan in place, the grand total behind
+        LBDRN_LAUNCH_CHECK();
+        k_part_scatter<<<dim3(nwg, count), 256, 0, s>>>(A, steps, npart, nwg);
+        LBDRN_LAUNCH_CHECK();
+        k_part_links<<<dim3(npart, count), LINK_THREADS, 0, s>>>(A, un);
+        LBDRN_LAUNCH_CHECK();
+        k_chase_batch<<<dim3((un + 255) / 256, count), 256, 0, s>>>(A, un, out);
+        LBDRN_LAUNCH_CHECK();
+        return 0;
+    }
     for (int c = 0; c < count; ++c) {
         uint32_t* j = w.j + (size_t)c * (w.arr / sizeof(uint32_t));
-        if (w.pairs && steps) {   // the partitioned path
-            const int nwg = (int)((steps + PART_CHUNK - 1) / PART_CHUNK), npart = (int)((un + PART_SIZE - 1) >> PART_SHIFT);
-            k_part_count<<<nwg, 256, 0, s>>>(j, steps, un, npart, nwg, w.histT);
-            LBDRN_LAUNCH_CHECK();
-            k_part_scan_rows<<<npart, 1024, 0, s>>>(w.histT, nwg, w.part_start);            // row totals -> part_start[partition]
-            LBDRN_LAUNCH_CHECK();
-            k_part_scan_rows<<<1, 1024, 0, s>>>(w.part_start, npart, w.part_start + npart);   // their exclusive scan in place, the grand total behind
-            LBDRN_LAUNCH_CHECK();
-            k_part_scatter<<<nwg, 256, 0, s>>>(j, steps, npart, nwg, w.histT, w.part_start, w.pairs);
-            LBDRN_LAUNCH_CHECK();
-            k_part_links<<<npart, LINK_THREADS, 0, s>>>(un, w.part_start, w.pairs, w.links, (int32_t*)w.cursor, (int32_t*)w.cnt);
-            LBDRN_LAUNCH_CHECK();
-            k_chase<<<(un + 255) / 256, 256, 0, s>>>(j, un, (const int32_t*)w.cursor, (const int32_t*)w.cnt, out + (size_t)c * n);
-            LBDRN_LAUNCH_CHECK();
-            continue;
-        }
         LBDRN_HIP_TRY(hipMemsetAsync(w.cnt, 0xFF, w.arr, s));   // head[] = -1
         if (steps) {
             k_link_targets<<<(steps + 255) / 256, 256, 0, s>>>(j, steps, un, (int32_t*)w.cnt, (int32_t*)w.off);
