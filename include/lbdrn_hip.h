@@ -190,6 +190,12 @@ size_t lbdrn_randperm_workspace(int64_t n, int32_t count);
  * The MT19937 recurrence is serial, so a fit generates the orders of all its epochs in one call. */
 int lbdrn_randperm(const uint64_t *seeds, int32_t count, int64_t n, int64_t *perm, void *workspace,
                    size_t workspace_bytes, void *stream);
+/* Host only, for tests: the jump polynomial of segment `segment` (1..31) of a long permutation's MT19937 stream --
+ * g(t) = t^(segment * words_per_segment) mod the generator's characteristic polynomial, as 624 words (coefficient of t^i
+ * = bit i % 32 of word i / 32).  A permutation longer than a segment is generated as segments side by side, each from
+ * the state x[J + k] = XOR over the set bits i of g of x[i + k] (x: the raw MT19937 word sequence, seeded state first).
+ * Returns words_per_segment, or a negative LBDRN_E_* code. */
+int64_t lbdrn_mt19937_jump_poly(int32_t segment, uint32_t *poly624);
 
 /* MSB-plane payload "LBB2" -- stands where the reference calls an external lossless codec for the MSB raster
  * (gdal_translate -of JP2OpenJPEG QUALITY=100 REVERSIBLE=YES, encode.py:137; read back at decode.py:69-73).

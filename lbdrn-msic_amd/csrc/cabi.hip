@@ -24,6 +24,7 @@ int plane_encode(const uint16_t* planes, int C, int H, int W, void* body, size_t
                  void* ws, size_t ws_bytes, hipStream_t s);
 int plane_decode(const void* body, size_t body_bytes, int C, int H, int W, uint16_t* planes, int* status, void* ws,
                  size_t ws_bytes, hipStream_t s);
+int64_t mt19937_jump_poly(int segment, uint32_t* out);
 int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, void* ws, size_t ws_bytes,
                    hipStream_t s);
 size_t weights_bound(int64_t n);
@@ -310,6 +311,12 @@ int lbdrn_randperm(const uint64_t* seeds, int32_t count, int64_t n, int64_t* per
     LBDRN_REQUIRE(n >= 0 && (perm || n == 0), "bad n or null output");
     NEED_DEVICE();
     return randperm_batch(seeds, count, n, perm, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int64_t lbdrn_mt19937_jump_poly(int32_t segment, uint32_t* poly624)
+{
+    LBDRN_REQUIRE(poly624, "null output");
+    return mt19937_jump_poly(segment, poly624);
 }
 
 size_t lbdrn_plane_bound(int32_t C, int32_t H, int32_t W) { return plane_bound(C, H, W); }

@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "mt_jump.inc"
 
 namespace lbdrn {
 
@@ -52,23 +53,46 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y)
 //    renewed and read three chunks ahead of their use (LDS operations of one wave complete in order; a DPP wave shift
 //    for x[k+1] costs more issue slots than the read).
 // Tempering and the "% (n - i)" are left to the first consumer, which has 4 M threads to do them with.
+//
+// Round 4: a permutation longer than MT_SEG words is generated as SEGMENTS side by side (blockIdx.y), each by one wave as
+// above: segment 0 from the seeded state, segment s >= 1 from the state window x[s MT_SEG .. +624) that k_mt_jump has
+// combined out of the first 20,560 words (mt_jump.inc) -- those come from a first launch of this kernel that stops at
+// `limit` and leaves the seeded state in x0.  27 waves for 71 us each instead of one for 1.86 ms.
 struct SeedList { uint32_t s[32]; };
-__global__ void __launch_bounds__(64) k_mt19937_raw(SeedList seeds, uint32_t n, uint32_t* __restrict__ jall, size_t jstride)
+struct MtPlan {
+    uint32_t seg;         // raw words per segment (a multiple of 624); with one segment in the grid it is not looked at
+    uint32_t limit;       // no raw index at or beyond this one is generated (the prefix launch: MT_PREFIX)
+    const uint32_t* win;  // [seed][MT_MAX_SEG - 1][624]: the states of segments 1.. (null: one segment)
+    uint32_t* x0;         // [seed][624]: the seeded state, for k_mt_jump (the prefix launch; else null)
+};
+__global__ void __launch_bounds__(64)
+    k_mt19937_raw(SeedList seeds, uint32_t n, uint32_t* __restrict__ jall, size_t jstride, MtPlan P)
 {
     __shared__ uint32_t st[MT_N + 16];
     const int lane = threadIdx.x;
+    const uint32_t sg = blockIdx.y;
     uint32_t* __restrict__ raw = jall + (size_t)blockIdx.x * jstride;
-    if (lane == 0) {  // init_genrand, as at::mt19937(seed)
-        uint32_t x = seeds.s[blockIdx.x];
-        st[0] = x;
-        for (int k = 1; k < MT_N; ++k) {
-            x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
-            st[k] = x;
+    if (sg == 0) {
+        if (lane == 0) {  // init_genrand, as at::mt19937(seed)
+            uint32_t x = seeds.s[blockIdx.x];
+            st[0] = x;
+            for (int k = 1; k < MT_N; ++k) {
+                x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)k;
+                st[k] = x;
+            }
+            if (n > 0) raw[n - 1] = n - 1;   // (position n-1 is its own target; the consumers leave it alone)
         }
-        if (n > 0) raw[n - 1] = n - 1;   // (position n-1 is its own target; the consumers leave it alone)
+    } else {
+        const uint32_t* __restrict__ w = P.win + ((size_t)blockIdx.x * (MT_MAX_SEG - 1) + (sg - 1)) * MT_N;
+        for (int k = lane; k < MT_N; k += 64) st[k] = w[k];
     }
     __syncthreads();
-    const uint32_t steps = n > 0 ? n - 1 : 0;
+    if (P.x0)
+        for (int k = lane; k < MT_N; k += 64) P.x0[(size_t)blockIdx.x * MT_N + k] = st[k];
+    const uint32_t all = n > 0 ? n - 1 : 0;
+    const uint32_t first = sg * P.seg;
+    uint32_t steps = (sg + 1 == gridDim.y || all - first < P.seg) ? all : first + P.seg;   // (the last segment takes what is left)
+    steps = steps < P.limit ? steps : P.limit;
     constexpr int NC = 10;   // chunks: words 64c + lane, the last one 48 wide
     uint32_t a[NC];
 #pragma unroll
@@ -106,9 +130,54 @@ __global__ void __launch_bounds__(64) k_mt19937_raw(SeedList seeds, uint32_t n, 
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // block boundary: the next block's first reads
         __builtin_amdgcn_wave_barrier();
     };
-    uint32_t base = 0;
+    uint32_t base = first;
     for (; base + MT_N <= steps; base += MT_N) block(base, true);
     if (base < steps) block(base, false);
+}
+
+// the states the segments 1.. start from: win[seed][s-1][m] = XOR over the set bits i of g_s of x[i + m] (mt_jump.inc),
+// x[0..624) = the seeded state, x[624 + r] = raw[r].  blockIdx = (segment - 1, seed, eighth of the polynomial): an eighth
+// is 78 words of g_s = 2,496 values of i and needs 3,119 words of x -- 15 KB of LDS with the zeros behind them, so that these workgroups fit on a
+// CU beside a training workgroup (146.5 of 160 KB) instead of waiting for a free one; the eighths meet in win[] by
+// atomic XOR (exact in any order).  The bits of g_s are wave-uniform: the loop over them is scalar, its body one LDS read.
+constexpr int JUMP_SPLIT = 8, JUMP_PW = MT_N / JUMP_SPLIT, JUMP_X = JUMP_PW * 32 + MT_N - 1, JUMP_THREADS = 640,
+              JUMP_ZERO = (JUMP_X + 31) & ~31;
+static_assert(MT_N % JUMP_SPLIT == 0 && (JUMP_SPLIT - 1) * JUMP_PW * 32 + JUMP_X <= MT_N + (int)MT_PREFIX, "k_mt_jump reads x[0 .. 624 + MT_PREFIX)");
+__global__ void __launch_bounds__(JUMP_THREADS)
+    k_mt_jump(const uint32_t* __restrict__ x0, const uint32_t* __restrict__ jall, size_t jstride,
+              const uint32_t* __restrict__ polys, uint32_t* __restrict__ win)
+{
+    __shared__ uint32_t xs[JUMP_ZERO + JUMP_THREADS];   // the words of x, then zeros: what an absent bit reads
+    const int tid = threadIdx.x;
+    xs[JUMP_ZERO + tid] = 0u;
+    const uint32_t* __restrict__ raw = jall + (size_t)blockIdx.y * jstride;
+    const int i0 = blockIdx.z * JUMP_PW * 32;
+    for (int k = tid; k < JUMP_X; k += JUMP_THREADS) {
+        const int idx = i0 + k;
+        xs[k] = idx < MT_N ? x0[(size_t)blockIdx.y * MT_N + idx] : raw[idx - MT_N];
+    }
+    __syncthreads();
+    const uint32_t* __restrict__ g = polys + (size_t)blockIdx.x * MT_N + blockIdx.z * JUMP_PW;
+    // the 78 words of the polynomial sit in two registers across the wave and are picked by v_readlane: a load per
+    // word would put a memory wait (the counter LDS reads share) into every turn of the loop
+    static_assert(JUMP_PW <= 128, "two registers hold the eighth");
+    const int lane = tid & 63;
+    const uint32_t g0 = lane < JUMP_PW ? g[lane] : 0u, g1 = 64 + lane < JUMP_PW ? g[64 + lane] : 0u;
+    uint32_t acc = 0;
+    for (int w = 0; w < JUMP_PW; ++w) {
+        uint32_t gw = w < 64 ? __builtin_amdgcn_readlane(g0, w) : __builtin_amdgcn_readlane(g1, w - 64);
+        while (gw) {   // four set bits per turn, so that four reads are in flight; a bit that is not there reads a zero
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int off = gw ? 32 * w + __builtin_ctz(gw) : JUMP_ZERO;
+                gw &= gw - 1;   // (0 stays 0)
+                v[u] = xs[off + tid];
+            }
+            acc ^= (v[0] ^ v[1]) ^ (v[2] ^ v[3]);
+        }
+    }
+    if (tid < MT_N) atomicXor(&win[((size_t)blockIdx.y * (MT_MAX_SEG - 1) + blockIdx.x) * MT_N + tid], acc);   // (every lane stays for the readlanes)
 }
 
 __device__ __forceinline__ uint32_t mt_target(uint32_t raw, uint32_t i, uint32_t n) { return i + mt_temper(raw) % (n - i); }
@@ -385,6 +454,7 @@ struct PermWs {
     int2* links;             // (previous head of the target's list, step) per pair
     int32_t *pred, *last;
     uint32_t *histT, *part_start;
+    uint32_t *x0, *win;      // seeded states [count][624]; segment states [count][MT_MAX_SEG - 1][624] (mt_jump.inc)
     size_t sn, shist, sstart;
     size_t arr, total;
 };
@@ -415,9 +485,19 @@ static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
         w->histT = (uint32_t*)p; p += w->shist * sizeof(uint32_t) * count;
         w->part_start = (uint32_t*)p; p += w->sstart * sizeof(uint32_t) * count;
     }
+    w->x0 = (uint32_t*)p; p += align_up((size_t)count * MT_N * sizeof(uint32_t), 256);
+    w->win = (uint32_t*)p; p += align_up((size_t)count * (MT_MAX_SEG - 1) * MT_N * sizeof(uint32_t), 256);
     w->arr = arr;
     w->total = (size_t)(p - (char*)ws);
     return 0;
+}
+
+int64_t mt19937_jump_poly(int segment, uint32_t* out)
+{
+    LBDRN_REQUIRE(segment >= 1 && segment < MT_MAX_SEG, "segment must be 1 .. 31");
+    const std::vector<uint32_t>& tab = mt_jump_polys();
+    memcpy(out, tab.data() + (size_t)(segment - 1) * MT_N, MT_N * sizeof(uint32_t));
+    return (int64_t)MT_SEG;
 }
 
 size_t randperm_workspace(int64_t n, int count)
@@ -449,8 +529,22 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
     // timing experiments only (the permutations are then garbage; the training kernels clamp what they read):
     // LBDRN_RANDPERM_DIAG bit 0 = no MT19937 launch, bit 1 = none of the launches behind it
     static const int diag = getenv("LBDRN_RANDPERM_DIAG") ? atoi(getenv("LBDRN_RANDPERM_DIAG")) : 0;
+    static const bool no_jump = getenv("LBDRN_RANDPERM_NOJUMP") != nullptr;   // A/B: one wave per permutation from end to end
+    const int nseg = no_jump ? 1 : (int)std::min<uint32_t>(MT_MAX_SEG, (steps + MT_SEG - 1) / MT_SEG);
+    const size_t jstride = w.arr / sizeof(uint32_t);
     if (!(diag & 1)) {
-        k_mt19937_raw<<<count, 64, 0, s>>>(sl, un, w.j, w.arr / sizeof(uint32_t));
+        if (nseg > 1) {
+            const uint32_t* polys = nullptr;
+            if (int rc = mt_jump_table_device(&polys)) return rc;
+            k_mt19937_raw<<<dim3(count, 1), 64, 0, s>>>(sl, un, w.j, jstride, MtPlan{0u, MT_PREFIX, nullptr, w.x0});
+            LBDRN_LAUNCH_CHECK();
+            LBDRN_HIP_TRY(hipMemsetAsync(w.win, 0, (size_t)count * (MT_MAX_SEG - 1) * MT_N * sizeof(uint32_t), s));
+            k_mt_jump<<<dim3(nseg - 1, count, JUMP_SPLIT), JUMP_THREADS, 0, s>>>(w.x0, w.j, jstride, polys, w.win);
+            LBDRN_LAUNCH_CHECK();
+            k_mt19937_raw<<<dim3(count, nseg), 64, 0, s>>>(sl, un, w.j, jstride, MtPlan{MT_SEG, 0xffffffffu, w.win, nullptr});
+        } else {
+            k_mt19937_raw<<<dim3(count, 1), 64, 0, s>>>(sl, un, w.j, jstride, MtPlan{0u, 0xffffffffu, nullptr, nullptr});
+        }
         LBDRN_LAUNCH_CHECK();
     }
     if (diag & 2) return 0;

@@ -1229,6 +1229,8 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     const size_t ncol = (size_t)std::max(net.F - 2 * g.P, 0);
     const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + 2 * (size_t)p.RP + (size_t)g.C * BR_TW) * 4;   // window + offsets + position table + labels
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
+    static const bool diag_skip = getenv("LBDRN_PREPARE_DIAG") != nullptr;   // timing experiments only: no row matrix is built (the fit then trains on whatever the buffer holds)
+    if (diag_skip) return 0;
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
         k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
     } else {

@@ -60,6 +60,7 @@ SIGNATURES = {
     "lbdrn_train_profile_mode": (ctypes.c_int, [_i32]),
     "lbdrn_randperm_workspace": (_sz, [_i64, _i32]),
     "lbdrn_randperm": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), _i32, _i64, _vp, _vp, _sz, _vp]),
+    "lbdrn_mt19937_jump_poly": (_i64, [_i32, _vp]),
     "lbdrn_plane_bound": (_sz, [_i32, _i32, _i32]),
     "lbdrn_plane_workspace": (_sz, [_i32, _i32, _i32]),
     "lbdrn_plane_encode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _sz, _vp, _vp, _sz, _vp]),

@@ -33,6 +33,21 @@ def test_full_size_is_a_permutation_and_matches(dev):
     assert torch.equal(torch.randperm(n, generator=g), got.cpu())
 
 
+@pytest.mark.parametrize("n", [159744, 159745, 159746, 2 * 159744 + 1, 2 * 159744 + 2, 3 * 159744 + 625, 31 * 159744 + 1,
+                               32 * 159744 + 1, 32 * 159744 + 2, 33 * 159744 + 77])
+def test_segment_boundaries_of_the_mt19937_jump(dev, n):
+    """A permutation longer than 159,744 draws has its MT19937 words generated as up to 32 segments side by side, each from a
+    state that k_mt_jump combined out of the first 20,560 words (csrc/mt_jump.inc); the last segment takes what is left.
+    n - 1 draws: one segment exactly, one word into the second, the 32-segment limit and beyond it -- on both link paths
+    (partitioned up to 2048^2, atomic above)."""
+    seeds = [3, 19920517, 2 ** 63 - 1]
+    got = ops.randperm(seeds, n, dev).cpu()
+    for c, seed in enumerate(seeds):
+        g = torch.Generator()
+        g.manual_seed(seed)
+        assert torch.equal(torch.randperm(n, generator=g), got[c]), (seed, n)
+
+
 def test_device_stream_replays_dataloader_order(dev):
     from torch.utils.data import DataLoader, TensorDataset
     n, bs, epochs = 1003, 64, 3

@@ -360,3 +360,49 @@ def test_constants_and_log_record_layout_equal_the_reference(tmp_path):
     lines = (tmp_path / "sub" / "dir" / "run.txt").read_text().splitlines()
     layout = [re.sub(r"\d", "d", re.match(r"^\[[^\]]*\]", ln).group(0)) + ln[ln.index("]") + 1:] for ln in lines]
     assert layout == G["log_layout"]
+
+
+def _mt19937_words(seed, total):
+    """x[0..total): the seeded state of at::mt19937(seed), then the raw (untempered) recurrence -- plain numpy, three
+    slices per regeneration (the recurrence reaches back 227 words)."""
+    n, m = 624, 397
+    x = np.zeros(((total + n - 1) // n + 1) * n, np.uint32)
+    v = seed & 0xFFFFFFFF
+    x[0] = v
+    for k in range(1, n):
+        v = (1812433253 * (v ^ (v >> 30)) + k) & 0xFFFFFFFF
+        x[k] = v
+    for base in range(0, len(x) - n, n):
+        for lo, hi in ((0, 227), (227, 454), (454, 624)):
+            a, b, c = x[base + lo:base + hi], x[base + lo + 1:base + hi + 1], x[base + lo + m:base + hi + m]
+            y = (a & np.uint32(0x80000000)) | (b & np.uint32(0x7FFFFFFF))
+            x[base + n + lo:base + n + hi] = c ^ (y >> np.uint32(1)) ^ np.where(b & np.uint32(1), np.uint32(0x9908B0DF), np.uint32(0))
+    return x[:total]
+
+
+def test_mt19937_jump_polynomials_reproduce_the_sequence():
+    """lbdrn_randperm generates a long permutation's MT19937 words as segments side by side; segment s starts from
+    x[J + k] = XOR over the set bits i of g_s of x[i + k], J = s * words_per_segment (csrc/mt_jump.inc).  Host-side
+    arithmetic only: checked here against a plain MT19937 for the first, second and last polynomial."""
+    from lbdrn_hip import _lib
+    L = ctypes.CDLL(_lib.lib_path())
+    L.lbdrn_mt19937_jump_poly.restype = ctypes.c_int64
+    L.lbdrn_mt19937_jump_poly.argtypes = [ctypes.c_int32, ctypes.c_void_p]
+    g = np.zeros(624, np.uint32)
+    seg = L.lbdrn_mt19937_jump_poly(1, g.ctypes.data)
+    assert seg > 0 and seg % 624 == 0
+    assert L.lbdrn_mt19937_jump_poly(0, g.ctypes.data) < 0 and L.lbdrn_mt19937_jump_poly(32, g.ctypes.data) < 0
+    x = _mt19937_words(19920517, 31 * seg + 624)
+    rs = np.random.RandomState(19920517)   # mt19937ar's init_genrand, as at::mt19937: a check of the helper, not of the library
+    assert np.array_equal(rs.get_state()[1], x[:624])
+    def temper(y):
+        y = int(y); y ^= y >> 11; y ^= (y << 7) & 0x9D2C5680; y ^= (y << 15) & 0xEFC60000; y ^= y >> 18
+        return y
+    assert [temper(v) for v in x[624:628]] == [int(v) for v in rs.randint(0, 2**32, size=4, dtype=np.uint32)]
+    for s in (1, 2, 31):
+        assert L.lbdrn_mt19937_jump_poly(s, g.ctypes.data) == seg
+        idx = np.nonzero(np.unpackbits(g.view(np.uint8), bitorder="little"))[0]
+        assert 1000 < len(idx) and idx[-1] < 19937
+        for k in (1, 2, 311, 623):
+            assert np.bitwise_xor.reduce(x[idx + k]) == x[s * seg + k], (s, k)
+        assert np.bitwise_xor.reduce(x[idx]) >> 31 == x[s * seg] >> 31   # word 0 of a state window: its top bit is all the recurrence reads
