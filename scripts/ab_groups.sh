@@ -3,7 +3,7 @@
 mkdir -p gpurun_out/grp
 for cfg in $1; do
   g=${cfg%%:*}; f=${cfg##*:}
-  LBDRN_FIT_GROUP=$g python bench.py --steps 24 --warmup 4 --in-flight $f --no-cpu-baseline > gpurun_out/grp/g${g}_f$f.json 2>>gpurun_out/grp/err.log || exit 1
+  LBDRN_FIT_GROUP=$g python bench.py --steps 24 --warmup 4 --in-flight $f --no-cpu-baseline --no-other-configs > gpurun_out/grp/g${g}_f$f.json 2>>gpurun_out/grp/err.log || exit 1
   python -c "
 import json
 d=json.loads(open('gpurun_out/grp/g${g}_f$f.json').read().strip().splitlines()[-1])
