@@ -129,6 +129,13 @@ int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *im
  * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
  * short (no drop_last, encode.py:69). */
 size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
+/* path of lbdrn_train_epoch may carry LBDRN_TRAIN_ALONE (path | LBDRN_TRAIN_ALONE): a HINT that nothing else of weight
+ * runs on the device beside this fit's steps (the reference's own situation: one image after another, run.sh:29-42).
+ * The fused bc = 64 step then also touches the head of the NEXT minibatch's rows before its loader wave ends -- a lone
+ * chain of short launches leaves the memory system idle most of the time, and the next launch's first requests end in
+ * a cache (-2.5 % per tile); with several fits in flight the same reads cost more than they return, so callers that
+ * keep fits in flight leave the flag out.  Performance only: every number is the same bit for bit with and without. */
+#define LBDRN_TRAIN_ALONE 0x800
 /* Once per image, before the first lbdrn_train_epoch on this workspace: builds the per-image state
  * the fused path keeps in the workspace (the [N][F+C] feature|label row matrix that replaces the
  * reference's host-side LBDRNDataset tensors, LBDRNdataset.py:141-142).  The workspace contents

@@ -15,7 +15,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
 int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
-                     size_t ws_bytes, hipStream_t s);
+                     size_t ws_bytes, hipStream_t s, bool alone);
 int train_profile_mode(int mode);
 size_t randperm_workspace(int64_t n, int count);
 size_t plane_bound(int C, int H, int W);
@@ -231,6 +231,8 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
     LBDRN_REQUIRE(img && msb && perm && params && exp_avg && exp_avg_sq, "null pointer");
     LBDRN_REQUIRE(n >= 0 && batch_size >= 1 && adam_step0 >= 0, "bad n/batch_size/adam_step0");
     NEED_DEVICE();
+    const bool alone = (path & LBDRN_TRAIN_ALONE) != 0;   // a hint (lbdrn_hip.h): performance only
+    path &= ~LBDRN_TRAIN_ALONE;
     const bool ok = mfma_train_supported(*g, *net);
     if (path == LBDRN_PATH_MFMA && !ok) {
         set_error("fused MFMA train kernel does not support this shape");
@@ -239,7 +241,7 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
     LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
     if (ok && path != LBDRN_PATH_GENERIC)
         return mfma_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
-                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
+                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream, alone);
     return generic_train_epoch(*g, *net, img, msb, perm, n, batch_size, params, exp_avg, exp_avg_sq,
                                adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -276,19 +278,21 @@ int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom* const* g, const lbd
                       g[f]->relative == g[0]->relative, "the fits of a group must have one shape (fit %d differs)", f);
     }
     LBDRN_REQUIRE(n >= 0 && batch_size >= 1 && adam_step0 >= 0, "bad n/batch_size/adam_step0");
+    const int32_t hint = count == 1 ? (path & LBDRN_TRAIN_ALONE) : 0;   // (a group is not alone)
+    path &= ~LBDRN_TRAIN_ALONE;
     LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
     NEED_DEVICE();
     // side by side on the fused step where the shape has one; otherwise (and for any shape the group launch does not
     // take) one after another: same numbers either way
     if (count > 1 && path != LBDRN_PATH_GENERIC && mfma_train_supported(*g[0], *net)) {
         const int rc = mfma_train_epoch_group(count, *g[0], *net, perm, n, batch_size, params, exp_avg, exp_avg_sq,
-                                              adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream);
+                                              adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream, false);
         if (rc != LBDRN_E_UNSUPPORTED) return rc;
     }
     for (int f = 0; f < count; ++f)
         if (int rc = lbdrn_train_epoch(g[f], net, img[f], msb[f], perm[f], n, batch_size, params[f], exp_avg[f],
                                        exp_avg_sq[f], adam_step0, lr, losses ? losses[f] : nullptr, workspace[f],
-                                       workspace_bytes, path, stream))
+                                       workspace_bytes, path | hint, stream))
             return rc;
     return 0;
 }

@@ -91,6 +91,6 @@ int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img
 
 int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net, const int64_t* const* perm, int64_t n,
                            int bs, float* const* params, float* const* m, float* const* v, int64_t step0, double lr,
-                           float* const* losses, void* const* ws, size_t ws_bytes, hipStream_t s);
+                           float* const* losses, void* const* ws, size_t ws_bytes, hipStream_t s, bool alone);
 
 }  // namespace lbdrn

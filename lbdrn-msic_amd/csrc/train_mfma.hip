@@ -636,6 +636,7 @@ struct TrainArgs {
     float* stage_out;       // (tile kernel) where to stage the NEXT minibatch's rows (or null)
     const int64_t* perm_next;
     int next_n;
+    int touch_row_bytes;    // (k_train_stream) bytes at the head of each of the next minibatch's rows the loader wave touches before it ends
     unsigned long long* stamps;  // diagnostic build only (-DLBDRN_TRAIN_STAMPS): [nwg][16] s_memtime
     unsigned long long* tl;      // diagnostic build only (-DLBDRN_TIMELINE): [steps][4] first start / last end of the step's two launches, 100 MHz
 };
@@ -1248,7 +1249,7 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
 // the numbers are those of `count` separate calls, bit for bit.
 int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net, const int64_t* const* perm, int64_t n,
                            int bs, float* const* params, float* const* m, float* const* v, int64_t step0, double lr,
-                           float* const* losses, void* const* ws, size_t ws_bytes, hipStream_t s)
+                           float* const* losses, void* const* ws, size_t ws_bytes, hipStream_t s, bool alone)
 {
     TrainArgs A;
     if (!make_train_plan(g, net, &A.p)) {
@@ -1303,6 +1304,11 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
         LBDRN_HIP_TRY(hipMemset(tl_buf, 0, (size_t)tl_steps * TL_SLOTS * sizeof(unsigned long long)));
     }
 #endif
+    static const int touch_alone = [] {   // LBDRN_TOUCH_ROW_BYTES: A/B (0 .. the row's bytes)
+        const char* e = getenv("LBDRN_TOUCH_ROW_BYTES");
+        const int v = e ? atoi(e) : 256;
+        return v < 0 ? 0 : (v > 832 ? 832 : v) / 4 * 4;
+    }();
     const int rows_per_wg = A.p.wave ? WB : TB;
     const dim3 red_grid((unsigned)(A.p.slab_floats / (4 * RED_LANES)), (unsigned)count);
     int64_t step = step0;
@@ -1339,6 +1345,7 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
         if (A.p.wave) A.stage_in = nullptr, A.stage_out = nullptr;   // the wave-local kernels gather for themselves
         A.perm_next = perm[0] + first + bs;
         A.next_n = (int)nextB;
+        A.touch_row_bytes = (alone && count == 1) ? touch_alone : 0;   // (LBDRN_TRAIN_ALONE; see k_train_stream's loader wave)
         if (int rc = dispatch_train(A, nwg, count, s)) return rc;
         if (g_prof_mode == 2)   // measurement only: the same launch again (it writes the same slabs and loss partials)
             if (int rc = dispatch_train(A, nwg, count, s)) return rc;
@@ -1433,9 +1440,9 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
 int mfma_train_epoch(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                      const uint16_t* msb, const int64_t* perm, int64_t n, int bs, float* params,
                      float* m, float* v, int64_t step0, double lr, float* losses, void* ws,
-                     size_t ws_bytes, hipStream_t s)
+                     size_t ws_bytes, hipStream_t s, bool alone)
 {
-    return mfma_train_epoch_group(1, g, net, &perm, n, bs, &params, &m, &v, step0, lr, &losses, &ws, ws_bytes, s);
+    return mfma_train_epoch_group(1, g, net, &perm, n, bs, &params, &m, &v, step0, lr, &losses, &ws, ws_bytes, s, alone);
 }
 
 }  // namespace lbdrn

@@ -9,6 +9,7 @@ _LIB_PATH = os.environ.get("LBDRN_HIP_LIB") or os.path.join(os.path.dirname(_HER
 PATH_AUTO, PATH_GENERIC, PATH_MFMA = 0, 1, 2
 EVAL_BACKGROUND = 0x200   # hint OR'ed into `path` of lbdrn_eval_sse
 EVAL_FAST = 0x400         # the per-epoch ranking pass in the tolerance arithmetic (lbdrn_hip.h)
+TRAIN_ALONE = 0x800       # hint OR'ed into `path` of lbdrn_train_epoch: nothing else in flight on the device (lbdrn_hip.h)
 
 
 class LbdrnError(RuntimeError):

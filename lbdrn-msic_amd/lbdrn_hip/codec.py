@@ -206,7 +206,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
         for e in range(1, epochs + 1):
             perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
             ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
-                            adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws)
+                            adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws, alone=alone)
             adam_steps += steps_per_epoch
             if e in eval_epochs:                                              # encode.py:104-117
                 k = eval_epochs.index(e)

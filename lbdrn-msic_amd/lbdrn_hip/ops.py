@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EVAL_BACKGROUND, EVAL_FAST, Geom, Net, PATH_AUTO, check, lib
+from ._lib import EVAL_BACKGROUND, EVAL_FAST, TRAIN_ALONE, Geom, Net, PATH_AUTO, check, lib
 
 
 def _call(fn, ref, *args):
@@ -175,8 +175,9 @@ class TrainWorkspace:
 
 
 def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_sq, adam_step0, lr,
-                losses=None, path=PATH_AUTO, ws=None):
-    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor."""
+                losses=None, path=PATH_AUTO, ws=None, alone=False):
+    """One trainer epoch in place (encode.py:157 inner loop).  perm: int64 device tensor.  alone: nothing else of
+    weight is in flight on the device (LBDRN_TRAIN_ALONE, lbdrn_hip.h: a performance hint, same numbers)."""
     _need_cuda(img, msb, perm, params, exp_avg, exp_avg_sq, losses)
     img = _u16(img.contiguous())
     msb = _u16(msb.contiguous())
@@ -190,7 +191,7 @@ def train_epoch(geom, net, img, msb, perm, batch_size, params, exp_avg, exp_avg_
     _call(lib().lbdrn_train_epoch, img, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
                                   _ptr(perm), perm.numel(), batch_size, _ptr(params), _ptr(exp_avg),
                                   _ptr(exp_avg_sq), adam_step0, float(lr), _ptr(losses), _ptr(ws.buf),
-                                  ws.nbytes, path)
+                                  ws.nbytes, path | (TRAIN_ALONE if alone else 0))
 
 
 def train_group_max():

@@ -129,6 +129,37 @@ def test_window_centre_columns_take_no_part_in_a_fit(dev):
         assert np.abs(pn - p0).max() > 0                                     # (the rest did train)
 
 
+def test_alone_hint_changes_no_number(dev):
+    """LBDRN_TRAIN_ALONE (lbdrn_hip.h) is a performance hint -- the fused step's loader wave then also touches the head of
+    the next minibatch's rows before it ends: the epoch leaves the same parameters, moments and losses bit for bit, on
+    every shape of step (the streamed bc = 64 one that acts on it; the generic and the wide ones that ignore it), with a
+    ragged last minibatch, and the group call refuses nothing when the flag rides on a group of one."""
+    rng = np.random.default_rng(11)
+    for (C, H, W, K, D, nl, bc, bs) in [(8, 70, 90, 5, 2, 2, 64, 512), (3, 33, 47, 4, 1, 1, 64, 256), (8, 40, 52, 5, 2, 2, 256, 512)]:
+        cfg = FeatCfg(False, False, 1.4, 12, True, True)
+        img = synthetic_tile(5, C, H, W)
+        msb, lab, mx = O.split_bits(img, K)
+        F = cfg.feature_dim(C, D)
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(F, bc, C, nl)
+        p0 = _params(rng, F, bc, C, nl)
+        perm = torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev)
+        img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+        steps = (H * W + bs - 1) // bs
+        for path in (GEN, MFMA):
+            got = []
+            for alone in (False, True):
+                p = torch.from_numpy(p0.copy()).to(dev)
+                m, v = torch.zeros_like(p), torch.zeros_like(p)
+                losses = torch.zeros(steps, dtype=torch.float32, device=dev)
+                ws = ops.TrainWorkspace(geom, net, bs, dev).prepare(img_d, msb_d, path)
+                for e in range(2):
+                    ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, e * steps, 1e-3, losses, path=path, ws=ws, alone=alone)
+                got.append([t.cpu().numpy().view(np.int32) for t in (p, m, v, losses)])
+            for a, b in zip(*got):
+                assert np.array_equal(a, b), (bc, path)
+
+
 def test_mfma_train_rejects_unsupported_shapes(dev):
     img = synthetic_tile(1, 4, 16, 16)
     msb, _, mx = O.split_bits(img, 5)

@@ -41,6 +41,9 @@ def test_loader_wave_index_load_reaches_its_wait_untouched(tmp_path):
             lines = [l.split("//")[0].strip() for l in dis.splitlines() if l.startswith("\t")]
             loads = [k for k, l in enumerate(lines) if l.startswith("global_load_dwordx2")]
             assert loads, f"{name}: the loader's index load was not found"
+            # the FIRST 8-byte load of the kernel is the inline-asm one; the loader wave's parting touch of the next
+            # minibatch's indices is an ordinary load whose wait the compiler places itself (on either side of a branch)
+            loads = loads[:1]
             for k in loads:
                 dst = _regs(lines[k].split()[1].rstrip(","))
                 assert len(dst) == 2, lines[k]
