@@ -133,7 +133,7 @@ size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t 
  * runs on the device beside this fit's steps (the reference's own situation: one image after another, run.sh:29-42).
  * The fused bc = 64 step then also touches the head of the NEXT minibatch's rows before its loader wave ends -- a lone
  * chain of short launches leaves the memory system idle most of the time, and the next launch's first requests end in
- * a cache (-2.5 % per tile); with several fits in flight the same reads cost more than they return, so callers that
+ * a cache (-1..2 % per tile); with several fits in flight the same reads cost more than they return, so callers that
  * keep fits in flight leave the flag out.  Performance only: every number is the same bit for bit with and without. */
 #define LBDRN_TRAIN_ALONE 0x800
 /* Once per image, before the first lbdrn_train_epoch on this workspace: builds the per-image state
