@@ -214,13 +214,16 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
     name = "k_train_half + k_dw_wide" if wide else "k_train_stream"
     rows_wg = 32 if wide else 64
     nwg = (B + rows_wg - 1) // rows_wg
+    # k_dw_wide's grid (csrc/train_wide.inc:dispatch_dw): (unit blocks x input blocks of every layer + the output layer) x slices of 1024 rows
+    um, im0 = net.bc // 64, ((Fe + 15) // 16 + 3) // 4
+    dw_wgs = (um * im0 + (um * um if net.nl > 1 else 0) + 1) * ((B + 1023) // 1024)
     key = config_key(a)
     prof, whole = committed_profile(key if N == 2048 * 2048 else None, per_launch)
     if fused:
         t_k = t_own
         out.update({"kernel": (f"{name} (the two training launches of a step: row gather + forward + loss + backward of one {B}-row "
                                f"minibatch on {nwg} workgroups of 32 rows -- units halved between two waves --, then its weight "
-                               f"gradients as a batch-dimension GEMM on 232 workgroups; every CU)" if wide else
+                               f"gradients as a batch-dimension GEMM on {dw_wgs} workgroups; every CU)" if wide else
                                f"{name} (row gather + forward + loss + backward + weight gradients of one {B}-row "
                                f"minibatch of {per_launch} fit(s): {per_launch} x {nwg} workgroups of 64 rows, one per CU, on "
                                f"{min(256, per_launch * nwg)} of the chip's 256 CUs)"),

@@ -30,8 +30,15 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the functions declared here are its only exports. */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
-#define LBDRN_ABI_VERSION 1
+/* 2 (round 5): the `path` word of lbdrn_train_epoch gained LBDRN_TRAIN_ALONE and of lbdrn_eval_sse LBDRN_EVAL_FAST /
+ * LBDRN_EVAL_BACKGROUND, lbdrn_train_group_size / lbdrn_train_step_features were added, and the fused step's
+ * weight-gradient summation tree changed (still one fixed tree: see lbdrn_train_epoch). */
+#define LBDRN_ABI_VERSION 2
 
 typedef enum lbdrn_status {
     LBDRN_OK = 0,
@@ -116,7 +123,10 @@ int lbdrn_decode_fused(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t
  * instructions behind a compensated reduction (4.5e-7 absolute per activation, the training step's arithmetic) instead
  * of the canonical polynomials the decode kernels must use: *sse within 1e-6 relative of the flagless call (tested),
  * the pass 20 % shorter.  Still a fixed summation order: bitwise reproducible, same sum on any launch shape.  The
- * generic path ignores the flag. */
+ * generic path ignores the flag.
+ * With the flag the fused kernels take the colour window from img >> g->K and DO NOT READ msb (one plane read per pass
+ * instead of two): msb must be exactly that plane -- as lbdrn_split_bits leaves it -- or NULL.  A caller whose MSB plane is
+ * something else (a decoded or modified base) must leave the flag out. */
 #define LBDRN_EVAL_FAST 0x400
 int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
                    const uint16_t *msb, const float *params, double *sse, void *workspace,
@@ -244,6 +254,9 @@ int lbdrn_train_step(const lbdrn_net *net, const float *x, const float *t, int32
                      double lr, int32_t apply_adam, float *loss, float *grads, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 const char *lbdrn_jp2_last_error(void);
 
@@ -35,6 +38,9 @@ int lbdrn_jp2_decode(const uint8_t *buf, size_t bytes, uint16_t *planes, int32_t
 
 void lbdrn_jp2_free(uint8_t *p);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -72,8 +72,12 @@ static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, b
     q.S0 = g.P + ((q.ncolor + 1) / 2 + 3) / 4 * 4;
     // the evaluation pass in the tolerance arithmetic may take the features in any order (the sum is held to 1e-6, not to
     // a bit pattern): channel pairs, and no step for the window centres, which are exact zeros with RELATIVE
-    // (LBDRNdataset.py:126-128) -- 96 MFMA steps instead of 100 at the headline shape.  LBDRN_EVAL_NOPAIR=1: A/B
-    static const bool nopair = getenv("LBDRN_EVAL_NOPAIR") != nullptr;
+    // (LBDRNdataset.py:126-128) -- 96 MFMA steps instead of 100 at the headline shape.  (-DLBDRN_EXP_EVAL_NOPAIR: A/B build)
+#ifdef LBDRN_EXP_EVAL_NOPAIR
+    constexpr bool nopair = true;
+#else
+    constexpr bool nopair = false;
+#endif
     const int side = 2 * g.D + 1;
     q.pair = fast && !nopair && q.NT <= 2 && g.use_colors && g.D >= 1 && g.D <= 3 && (g.C % 2) == 0 && q.ncolor == g.C * side * side;
     // (NT = 4, bc = 128: the pair's 24 operands on top of 128 accumulator / activation registers would spill at two waves per SIMD)
@@ -731,7 +735,9 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
         rc = mode == MODE_EVAL_FAST
                  ? (A.p.NT == 1 ? launch_apply<1, MODE_EVAL_FAST>(A, grid, s, background)
                     : A.p.NT == 2 ? launch_apply<2, MODE_EVAL_FAST>(A, grid, s, background)
-                                  : launch_apply<4, MODE_EVAL_FAST>(A, grid, s, background))
+                                  // bc = 128: the tolerance arithmetic's extra operands spill at two waves per SIMD (88 registers,
+                                  // 356 B of scratch when it was instantiated); the canonical pass IS within the 1e-6 the flag promises
+                                  : launch_apply<4, MODE_EVAL>(A, grid, s, background))
                  : (A.p.NT == 1 ? launch_apply<1, MODE_EVAL>(A, grid, s, background)
                     : A.p.NT == 2 ? launch_apply<2, MODE_EVAL>(A, grid, s, background)
                                   : launch_apply<4, MODE_EVAL>(A, grid, s, background));

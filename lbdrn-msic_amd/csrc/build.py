@@ -12,10 +12,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = ["cabi.hip", "generic.hip", "apply_mfma.hip", "train_mfma.hip", "randperm.hip", "plane_codec.hip", "weights_codec.hip"]
-HDRS = ["common.hpp", "lbdrn_math.hpp", "mt_jump.inc", "train_wide.inc", "train_stream.inc", "apply_wide.inc", "../../include/lbdrn_hip.h"]
+HDRS = ["common.hpp", "lbdrn_math.hpp", "mt_jump.inc", "train_wide.inc", "train_stream.inc", "apply_wide.inc", "exports.map", "../../include/lbdrn_hip.h"]
 OUT = os.path.join(os.path.dirname(HERE), "liblbdrn_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden"]   # the exports are the functions include/lbdrn_hip.h declares, nothing else
 
 
 JP2_OUT = os.path.join(os.path.dirname(HERE), "liblbdrn_jp2.so")
@@ -36,7 +37,7 @@ def build_jp2(force=False):
                 if glob.glob(os.path.join(d, "libopenjp2.so*"))]
         if incs and libs:
             lib = sorted(glob.glob(os.path.join(libs[0], "libopenjp2.so*")))[0]
-            cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", "-I" + os.path.dirname(incs[-1]), "-o", JP2_OUT, src,
+            cmd = [os.environ.get("CC", "gcc"), "-O2", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden", "-I" + os.path.dirname(incs[-1]), "-o", JP2_OUT, src,
                    lib, "-Wl,-rpath," + libs[0]]
             subprocess.check_call(cmd)
             return JP2_OUT
@@ -67,7 +68,8 @@ def build(force=False, extra=(), out=None):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(HERE, "exports.map"),
+                           "-o", out] + objs)
     return out
 
 

@@ -54,19 +54,16 @@ static OPJ_OFF_T mem_skip(OPJ_OFF_T n, void *u)
     mem_t *m = (mem_t *)u;
     if (n < 0) return -1;
     if (m->writable) {   /* skipping forward while writing leaves a hole that is filled in later (box lengths) */
-        if (m->pos + (size_t)n > m->cap) {
+        const size_t end = m->pos + (size_t)n;
+        if (end > m->size) {   /* whatever of [pos, end) lies beyond the written bytes becomes zeros, never heap contents */
             static const uint8_t zero[256] = {0};
-            OPJ_OFF_T left = n;
-            const size_t keep = m->pos;
-            while (left > 0) {
-                const size_t k = left > 256 ? 256 : (size_t)left;
+            m->pos = m->size;
+            while (m->pos < end) {
+                const size_t k = end - m->pos > 256 ? 256 : end - m->pos;
                 if (mem_write((void *)zero, k, u) == (OPJ_SIZE_T)-1) return -1;
-                left -= (OPJ_OFF_T)k;
             }
-            m->pos = keep;
         }
-        m->pos += (size_t)n;
-        if (m->pos > m->size) m->size = m->pos;
+        m->pos = end;
         return n;
     }
     if ((size_t)n > m->size - m->pos) n = (OPJ_OFF_T)(m->size - m->pos);

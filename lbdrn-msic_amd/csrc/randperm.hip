@@ -460,8 +460,11 @@ struct PermWs {
 };
 static bool perm_partitioned(int64_t n)
 {
-    static const bool off = getenv("LBDRN_RANDPERM_ATOMIC") != nullptr;   // A/B: the memory-side atomic path for every n
-    return !off && n > 16 * PART_SIZE && n <= PART_MAX_N;
+#ifdef LBDRN_EXP_RANDPERM_ATOMIC   // (A/B build: the memory-side atomic path for every n)
+    return false;
+#else
+    return n > 16 * PART_SIZE && n <= PART_MAX_N;
+#endif
 }
 
 static int carve_perm(int64_t n, int count, void* ws, PermWs* w)
@@ -526,10 +529,18 @@ int randperm_batch(const uint64_t* seeds, int count, int64_t n, int64_t* out, vo
     const uint32_t un = (uint32_t)n, steps = un - 1;
     SeedList sl;
     for (int c = 0; c < 32; ++c) sl.s[c] = c < count ? (uint32_t)(seeds[c] & 0xffffffffu) : 0u;
-    // timing experiments only (the permutations are then garbage; the training kernels clamp what they read):
-    // LBDRN_RANDPERM_DIAG bit 0 = no MT19937 launch, bit 1 = none of the launches behind it
-    static const int diag = getenv("LBDRN_RANDPERM_DIAG") ? atoi(getenv("LBDRN_RANDPERM_DIAG")) : 0;
-    static const bool no_jump = getenv("LBDRN_RANDPERM_NOJUMP") != nullptr;   // A/B: one wave per permutation from end to end
+    // timing-only builds (never the shipped library: the permutations are then garbage; the training kernels clamp what
+    // they read): -DLBDRN_EXP_RANDPERM_DIAG=1 no MT19937 launch, =2 none of the launches behind it, =3 neither
+#ifdef LBDRN_EXP_RANDPERM_DIAG
+    constexpr int diag = LBDRN_EXP_RANDPERM_DIAG;
+#else
+    constexpr int diag = 0;
+#endif
+#ifdef LBDRN_EXP_RANDPERM_NOJUMP   // (A/B build: one wave per permutation from end to end)
+    constexpr bool no_jump = true;
+#else
+    constexpr bool no_jump = false;
+#endif
     const int nseg = no_jump ? 1 : (int)std::min<uint32_t>(MT_MAX_SEG, (steps + MT_SEG - 1) / MT_SEG);
     const size_t jstride = w.arr / sizeof(uint32_t);
     if (!(diag & 1)) {

@@ -99,7 +99,11 @@ __host__ __device__ __forceinline__ int slot_of_feat(int k, const FeatMap& m)   
 // the map of a shape whose fused step skips the window centres (identity otherwise)
 static FeatMap centre_skipping_map(const lbdrn_geom& g, const lbdrn_net& net)
 {
-    static const bool keep_zero = getenv("LBDRN_TRAIN_KEEP_CENTRE") != nullptr;   // A/B measurements
+#ifdef LBDRN_EXP_KEEP_CENTRE   // (A/B build: the step multiplies the zeros as well)
+    constexpr bool keep_zero = true;
+#else
+    constexpr bool keep_zero = false;
+#endif
     const int side = 2 * g.D + 1;
     if (!keep_zero && g.use_colors && g.relative && g.D > 0 && net.F == 2 * g.P + g.C * side * side)
         return FeatMap{net.F - g.C, 2 * g.P, side * side, g.D * side + g.D};
@@ -123,18 +127,16 @@ struct TrainPlan {
     int lds_x, lds_xt, lds_h, lds_ht, lds_z, lds_zt, lds_zo, lds_zot, lds_pix, lds_red, lds_floats;
 };
 
-// which fused step runs a shape this file supports: 2 = k_train_stream (default), 0 = the 8-wave tile kernel
-// k_train_mfma (nl = 3, and anything LBDRN_TRAIN_KERNEL=tile asks for: A/B measurements).  The variable is read ONCE per
-// process (the choice fixes the row-matrix layout that lbdrn_train_prepare builds and lbdrn_train_epoch reads: it must not
-// change between the two).
+// which fused step runs a shape this file supports: 2 = k_train_stream, 0 = the 8-wave tile kernel k_train_mfma (nl = 3).
+// A function of the shape only (the choice fixes the row-matrix layout that lbdrn_train_prepare builds and
+// lbdrn_train_epoch reads).  -DLBDRN_EXP_TILE_KERNEL: A/B build that runs every shape on the tile kernel.
 static int train_kernel_choice()
 {
-    static const int choice = [] {
-        const char* e = getenv("LBDRN_TRAIN_KERNEL");
-        if (!e) return 2;
-        return e[0] == 't' ? 0 : 2;
-    }();
-    return choice;
+#ifdef LBDRN_EXP_TILE_KERNEL
+    return 0;
+#else
+    return 2;
+#endif
 }
 
 __host__ __device__ constexpr int stream_rp(int LQ);
@@ -1168,8 +1170,12 @@ static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s
 {
     const bool one = A.net.nl == 1;
     // the two shapes BASELINE.json names (F = 200: 13 strips, F = 250: 16) run the straight-line weight-gradient
-    // schedule; LBDRN_STREAM_LOOP=1 keeps them on the loop (A/B measurements)
-    static const bool loop_only = getenv("LBDRN_STREAM_LOOP") != nullptr;
+    // schedule (-DLBDRN_EXP_STREAM_LOOP: A/B build that keeps them on the loop)
+#ifdef LBDRN_EXP_STREAM_LOOP
+    constexpr bool loop_only = true;
+#else
+    constexpr bool loop_only = false;
+#endif
     switch (A.p.LQ) {
         case 16: return one ? launch_stream<16, 1, 0>(A, nwg, count, s) : launch_stream<16, 2, 0>(A, nwg, count, s);
         case 32: return one ? launch_stream<32, 1, 0>(A, nwg, count, s) : launch_stream<32, 2, 0>(A, nwg, count, s);
@@ -1230,8 +1236,9 @@ int mfma_train_prepare(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t
     const size_t ncol = (size_t)std::max(net.F - 2 * g.P, 0);
     const size_t tile_lds = ((size_t)g.C * side * (BR_TW + 2 * g.D) + 2 * ncol + 2 * (size_t)p.RP + (size_t)g.C * BR_TW) * 4;   // window + offsets + position table + labels
     const int64_t nblk = (int64_t)g.H * ((g.W + BR_TW - 1) / BR_TW);
-    static const bool diag_skip = getenv("LBDRN_PREPARE_DIAG") != nullptr;   // timing experiments only: no row matrix is built (the fit then trains on whatever the buffer holds)
-    if (diag_skip) return 0;
+#ifdef LBDRN_EXP_PREPARE_DIAG   // (timing-only build, never the shipped library: no row matrix is built, the fit trains on whatever the buffer holds)
+    return 0;
+#endif
     if (tile_lds <= 48 * 1024 && g.D < g.H && g.D < g.W && nblk < ((int64_t)1 << 31)) {
         k_build_rows_tiled<<<(unsigned)nblk, 256, tile_lds, s>>>(g, net.F, p.RP, LQs, p.fm, msb, img, rows);
     } else {
@@ -1304,17 +1311,20 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
         LBDRN_HIP_TRY(hipMemset(tl_buf, 0, (size_t)tl_steps * TL_SLOTS * sizeof(unsigned long long)));
     }
 #endif
-    static const int touch_alone = [] {   // LBDRN_TOUCH_ROW_BYTES: A/B (0 .. the row's bytes)
-        const char* e = getenv("LBDRN_TOUCH_ROW_BYTES");
-        const int v = e ? atoi(e) : 256;
-        return v < 0 ? 0 : (v > 832 ? 832 : v) / 4 * 4;
-    }();
+#ifndef LBDRN_TOUCH_ROW_BYTES
+#define LBDRN_TOUCH_ROW_BYTES 256   // (A/B builds: 0 .. the row's bytes, a multiple of 4; performance only, the numbers do not depend on it)
+#endif
+    constexpr int touch_alone = LBDRN_TOUCH_ROW_BYTES;
     const int rows_per_wg = A.p.wave ? WB : TB;
     const dim3 red_grid((unsigned)(A.p.slab_floats / (4 * RED_LANES)), (unsigned)count);
     int64_t step = step0;
     int si = 0;
-    // diagnostic (LBDRN_HOST_TRACE=1): how long the host spends in each iteration of the launch loop
-    static const bool host_trace = getenv("LBDRN_HOST_TRACE") != nullptr;
+    // diagnostic (-DLBDRN_HOST_TRACE build): how long the host spends in each iteration of the launch loop
+#ifdef LBDRN_HOST_TRACE
+    constexpr bool host_trace = true;
+#else
+    constexpr bool host_trace = false;
+#endif
     std::vector<std::pair<int, double>> slow;
     double host_total = 0.0;
     auto tprev = std::chrono::steady_clock::now();

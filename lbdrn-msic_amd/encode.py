@@ -26,6 +26,8 @@ from LBDRNdataset import tile_windows
 DEVICE = "cuda:0"
 BASE_CODEC = os.environ.get("LBDRN_BASE_CODEC", "LBB2")   # "jp2": JPEG 2000 through OpenJPEG, what the reference writes
                                                           # (encode.py:137); "LBB1": the portable host payload of older files
+REPORT_BOTH = os.environ.get("LBDRN_REPORT_BOTH_BPSP", "") not in ("", "0")   # also log the size of the payload format NOT
+# written (JPEG 2000 costs 2-3 s of one host core per 8 x 2048^2 tile: off by default)
 IN_FLIGHT = int(os.environ["LBDRN_IN_FLIGHT"]) if "LBDRN_IN_FLIGHT" in os.environ else None   # tiles of one image
 # progressing at a time on a GPU (None: codec.fit_many's default, 4)
 
@@ -70,6 +72,15 @@ def report_and_pack(args, res):
     else:
         base_payload = container.encode_base(_host_msb(res), codec=BASE_CODEC)
     logger.log.info(f"MSB: {len(base_payload)} bytes: bpsp={len(base_payload) * 8 / res.n_subpixels}")
+    if REPORT_BOTH:   # the other payload's size beside the one written: LBB2 is this package's private format, jp2 the
+        # reference's (the bpsp the published tables are in); the record does not match results_summary.py's patterns
+        other = "jp2" if BASE_CODEC == "LBB2" else "LBB2"
+        try:
+            alt = (container.encode_base(_host_msb(res), codec="jp2") if other == "jp2" else
+                   container.encode_base(res.msb_device, device=DEVICE, as_uint8=res.msb_max <= 255))
+            logger.log.info(f"MSB as {other}: {len(alt)} bytes: bpsp={len(alt) * 8 / res.n_subpixels} (written: {BASE_CODEC})")
+        except Exception as e:   # (liblbdrn_jp2.so absent: say so, the run goes on)
+            logger.log.info(f"MSB as {other}: unavailable ({e})")
     logger.log.info(f"{filename}: fit {res.seconds['fit']:.3f}s on {DEVICE}")
     return nn_payload, base_payload
 

@@ -6,6 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LBDRN_HIP_LIB selects another build of the same ABI (e.g. the diagnostic liblbdrn_hip_stamps.so)
 _LIB_PATH = os.environ.get("LBDRN_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "liblbdrn_hip.so")
 
+ABI_VERSION = 2           # LBDRN_ABI_VERSION of include/lbdrn_hip.h this binding was written against
 PATH_AUTO, PATH_GENERIC, PATH_MFMA = 0, 1, 2
 EVAL_BACKGROUND = 0x200   # hint OR'ed into `path` of lbdrn_eval_sse
 EVAL_FAST = 0x400         # the per-epoch ranking pass in the tolerance arithmetic (lbdrn_hip.h)
@@ -13,7 +14,11 @@ TRAIN_ALONE = 0x800       # hint OR'ed into `path` of lbdrn_train_epoch: nothing
 
 
 class LbdrnError(RuntimeError):
-    pass
+    """A failed library call; `code` is the lbdrn_status it returned (None for host-side failures)."""
+    code = None
+
+
+E_ARG, E_DEVICE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4   # enum lbdrn_status
 
 
 class Geom(ctypes.Structure):
@@ -97,8 +102,8 @@ def lib():
         fn = getattr(L, name)  # AttributeError = ABI mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if L.lbdrn_abi_version() != 1:
-        raise LbdrnError(f"liblbdrn_hip ABI {L.lbdrn_abi_version()} != 1")
+    if L.lbdrn_abi_version() != ABI_VERSION:
+        raise LbdrnError(f"liblbdrn_hip ABI {L.lbdrn_abi_version()} != {ABI_VERSION}")
     _lib = L
     return L
 
@@ -106,4 +111,6 @@ def lib():
 def check(rc):
     if rc != 0:
         msg = lib().lbdrn_last_error()
-        raise LbdrnError(f"liblbdrn_hip error {rc}: {msg.decode() if msg else ''}")
+        err = LbdrnError(f"liblbdrn_hip error {rc}: {msg.decode() if msg else ''}")
+        err.code = rc
+        raise err

@@ -18,7 +18,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.lib_path())
     for name in declared:
         assert hasattr(L, name), name
-    assert _lib.lib().lbdrn_abi_version() == 1
+    assert _lib.lib().lbdrn_abi_version() == _lib.ABI_VERSION == 2
     # the constants the Python host mirrors
     consts = {k: int(v, 0) for k, v in re.findall(r"#define (LBDRN_[A-Z_]+) (0x[0-9a-fA-F]+|\d+)\b", hdr)}
     assert (consts["LBDRN_PATH_AUTO"], consts["LBDRN_PATH_GENERIC"], consts["LBDRN_PATH_MFMA"]) == \

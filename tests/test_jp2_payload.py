@@ -66,6 +66,59 @@ def test_damaged_and_foreign_streams_are_refused(jp2):
         jp2.encode(np.zeros((1, 4, 4), np.int32))
 
 
+def _pillow_jp2():
+    try:
+        from PIL import Image, features
+    except ImportError:
+        pytest.skip("Pillow is not installed")
+    if not features.check("jpg_2000"):
+        pytest.skip("this Pillow has no JPEG 2000 codec")
+    return Image, features.version("jpg_2000")
+
+
+def test_interop_with_a_second_openjpeg_build(jp2, tmp_path):
+    """VERDICT round 4 item 5, the reviewer's hand check as a test: Pillow bundles an OpenJPEG of its own (2.5.x; the shim
+    links the image's 2.4.0), so streams that cross between the two are checked by an independent build of the codec --
+    what `jp2.encode` writes Pillow decodes bit-exactly (1 band x 16 bit, 3 bands x 8 bit), and what Pillow writes
+    reversibly (one tile and several, raw codestream and .jp2 file) `jp2.decode` reads bit-exactly.  That is as far as
+    the reference's own payload (GDAL -> OpenJPEG, encode.py:137 / decode.py:69-73) can be pinned without GDAL."""
+    import io
+    Image, version = _pillow_jp2()
+    rng = np.random.default_rng(7)
+    smooth = (np.add.outer(np.arange(150) * 37, np.arange(211) * 11) % 9000).astype(np.uint16)
+    g16 = (smooth + rng.integers(0, 40, smooth.shape)).astype(np.uint16)                       # [H, W], up to 9039
+    rgb8 = rng.integers(0, 256, (97, 130, 3)).astype(np.uint8)
+    rgb8[..., 1] = (np.add.outer(np.arange(97), np.arange(130)) % 256).astype(np.uint8)
+    # ours -> Pillow
+    im = Image.open(io.BytesIO(jp2.encode(g16[None])))
+    im.load()
+    assert im.mode in ("I;16", "I;16L", "I;16B", "I") and np.array_equal(np.asarray(im).astype(np.uint16), g16), (version, im.mode)
+    im = Image.open(io.BytesIO(jp2.encode(np.ascontiguousarray(rgb8.transpose(2, 0, 1)))))
+    im.load()
+    assert im.mode == "RGB" and np.array_equal(np.asarray(im), rgb8), (version, im.mode)
+    # Pillow -> ours: reversible wavelet, no colour transform on the multi-band image, single- and multi-tile, both containers
+    survived = 0
+    for arr, planes in ((g16, g16[None]), (rgb8, rgb8.transpose(2, 0, 1))):
+        for ext in ("jp2", "j2k"):
+            for tile in (None, (64, 64)):
+                path = tmp_path / f"p_{arr.ndim}_{ext}_{'t' if tile else 'o'}.{ext}"
+                kw = dict(irreversible=False, mct=0)
+                if tile:
+                    kw["tile_size"] = tile
+                Image.fromarray(arr).save(str(path), **kw)
+                raw = path.read_bytes()
+                assert jp2.is_jp2(raw)
+                got = jp2.decode(raw)
+                # the judge of a stream is the OTHER build's decoder (Pillow 12's tiled writer mangles 16-bit input --
+                # its own decoder does not give the source back either --, so the source is compared where it survives)
+                back = np.asarray(Image.open(str(path)))
+                back = back[None] if back.ndim == 2 else back.transpose(2, 0, 1)
+                assert got.dtype == planes.dtype and np.array_equal(got, back.astype(planes.dtype)), (version, ext, tile, arr.shape)
+                if np.array_equal(back, planes):
+                    survived += 1
+    assert survived >= 6, survived    # (every case but the two tiled 16-bit ones)
+
+
 @pytest.mark.gpu
 def test_cli_round_trip_with_the_jpeg2000_payload(jp2, dev, tmp_path):
     """LBDRN_BASE_CODEC=jp2: encode.py writes the MSB planes as a JP2 file inside the .bin (where the reference's
@@ -78,7 +131,7 @@ def test_cli_round_trip_with_the_jpeg2000_payload(jp2, dev, tmp_path):
     raster_io.write_raster(str(src), img)
     recs = {}
     for codec_name in ("jp2", "LBB2"):
-        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"), LBDRN_BASE_CODEC=codec_name)
+        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"), LBDRN_BASE_CODEC=codec_name, LBDRN_REPORT_BOTH_BPSP="1")
         out = tmp_path / codec_name
         subprocess.run([sys.executable, os.path.join(ROOT, "lbdrn-msic_amd", "encode.py"), "-i", str(src), "-o", str(out),
                         "-K", "5", "-D", "2", "-bs", "256", "-e", "2"], check=True, env=env, capture_output=True)
@@ -94,5 +147,9 @@ def test_cli_round_trip_with_the_jpeg2000_payload(jp2, dev, tmp_path):
         sys.argv = ["decode.py"]
         assert dec_mod.main(["-i", str(outdir / "tile.bin")]) == 0
         recs[codec_name] = raster_io.read_raster(str(outdir / "tile_recon.tif"))
-        assert re.search(r"MSB: (\d+) bytes", (outdir / "encode.txt").read_text())
+        log = (outdir / "encode.txt").read_text()
+        assert re.search(r"MSB: (\d+) bytes", log)
+        # LBDRN_REPORT_BOTH_BPSP: the other format's size rides along, in a record the summary's patterns do not match
+        other = re.search(r"MSB as (jp2|LBB2): (\d+) bytes: bpsp=", log)
+        assert other and other.group(1) == ("LBB2" if codec_name == "jp2" else "jp2") and len(re.findall(r"MSB: \d+ bytes", log)) == 1
     assert np.array_equal(recs["jp2"], recs["LBB2"]) and np.array_equal(recs["jp2"] >> 5, img >> 5)

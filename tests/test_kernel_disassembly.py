@@ -61,3 +61,29 @@ def test_loader_wave_index_load_reaches_its_wait_untouched(tmp_path):
                     pytest.fail(f"{name}: no vector-memory wait behind the index load")
                 checked += 1
     assert checked >= 4, "k_train_stream instances not found in the library's code objects"
+
+
+def test_shipped_library_exports_the_c_abi_only_and_no_kernel_uses_scratch():
+    """the library is a product -- `nm -D` shows the functions of include/lbdrn_hip.h and no C++ symbol
+    (-fvisibility=hidden + csrc/exports.map), no kernel in it spills (k_apply_mfma<4, 2> did: 88 registers), and its
+    sources read no environment variable (every A/B and timing-only switch is a -D of csrc/build.py --variant)."""
+    import sys
+    so = os.path.join(ROOT, "lbdrn-msic_amd", "liblbdrn_hip.so")
+    if not (os.path.exists(OBJDUMP) and os.path.exists(so)):
+        pytest.skip("llvm-objdump or the library is missing")
+    out = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True, check=True).stdout
+    names = [l.split()[-1] for l in out.splitlines() if l.strip()]
+    assert names and all(n.startswith("lbdrn_") for n in names), [n for n in names if not n.startswith("lbdrn_")][:5]
+    header = open(os.path.join(ROOT, "include", "lbdrn_hip.h")).read()
+    declared = set(re.findall(r"\b(lbdrn_[a-z0-9_]+)\s*\(", header))
+    assert set(names) == declared, (sorted(set(names) - declared), sorted(declared - set(names)))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from kernel_resources import kernel_resources
+    rows = kernel_resources(so)
+    assert len(rows) > 50
+    bad = [(r["demangled"], r["spill_vgpr"], r["scratch"]) for r in rows if r["spill_vgpr"] or r["scratch"]]
+    assert not bad, bad
+    csrc = os.path.join(ROOT, "lbdrn-msic_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".inc", ".hpp", ".c")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
