@@ -133,6 +133,14 @@ def overlap_evaluation(dev, alone):
     return alone_streams_fit_queues()
 
 
+def background_steps(steps_per_epoch):
+    """How many steps of an epoch a lone fit takes on the half-chip launch, beside the previous epoch's background
+    evaluation pass (fit_device).  The pass reads the image once on half as many workgroups: 2.8 ms at the headline shape =
+    0.27 of an epoch's 512 steps of 20 us; LBDRN_LONE_HEAD_FRAC overrides the fraction (A/B)."""
+    frac = float(os.environ.get("LBDRN_LONE_HEAD_FRAC", "0.27"))
+    return int(round(frac * steps_per_epoch))
+
+
 def _eval_stream(dev, main):
     """The stream a lone fit's evaluation passes run on: one of the fit streams (none is busy when a fit is alone),
     not a stream of its own -- a process that uses more streams than the device has hardware queues makes streams
@@ -205,8 +213,16 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     try:
         for e in range(1, epochs + 1):
             perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
-            ops.train_epoch(geom, net, img_d, msb_d, perm, batch_size, params, exp_avg, exp_avg_sq,
-                            adam_steps, lrs[e - 1], losses[e - 1] if keep_losses else None, path, train_ws, alone=alone)
+            # While the previous epoch's evaluation pass runs in the background it holds half of the CUs: the steps beside
+            # it go out WITHOUT the alone hint -- the half-chip launch that fits on the other half (k_train_stream) --, the
+            # rest of the epoch with it (k_train_split, every CU).  Same numbers either way (lbdrn_hip.h: the hint
+            # changes no bit), so where the line is drawn is a matter of time only.
+            head = min(steps_per_epoch, background_steps(steps_per_epoch)) if (side is not None and alone and e - 1 in eval_epochs) else 0
+            for lo, hi, hint in ((0, head, False), (head, steps_per_epoch, alone)):
+                if hi > lo:
+                    ops.train_epoch(geom, net, img_d, msb_d, perm[lo * batch_size:hi * batch_size], batch_size, params, exp_avg,
+                                    exp_avg_sq, adam_steps + lo, lrs[e - 1], losses[e - 1][lo:hi] if keep_losses else None, path,
+                                    train_ws, alone=hint)
             adam_steps += steps_per_epoch
             if e in eval_epochs:                                              # encode.py:104-117
                 k = eval_epochs.index(e)

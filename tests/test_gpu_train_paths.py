@@ -130,13 +130,20 @@ def test_window_centre_columns_take_no_part_in_a_fit(dev):
 
 
 def test_alone_hint_changes_no_number(dev):
-    """LBDRN_TRAIN_ALONE (lbdrn_hip.h) is a performance hint -- the fused step's loader wave then also touches the head of
-    the next minibatch's rows before it ends: the epoch leaves the same parameters, moments and losses bit for bit, on
-    every shape of step (the streamed bc = 64 one that acts on it; the generic and the wide ones that ignore it), with a
-    ragged last minibatch, and the group call refuses nothing when the flag rides on a group of one."""
+    """LBDRN_TRAIN_ALONE (lbdrn_hip.h) is a performance hint: the epoch leaves the same parameters, moments and losses bit
+    for bit with and without it, on every shape of step.  Since round 5 that is a statement about TWO kernels: the shapes
+    BASELINE.json names (F = 200 and the embedding's F = 250 at bc = 64, two hidden layers) step on k_train_split -- 256
+    workgroups of 32 rows, units halved between two waves, two gradient slabs per 64-row group -- when the caller says the
+    fit has the device to itself, and on k_train_stream (128 workgroups of 64 rows) otherwise; both follow one summation
+    tree (train_split.inc), so which of them ran must not show in a single bit.  Ragged last minibatches (a group with one
+    parity half-empty, a minibatch shorter than a workgroup), odd batch sizes; the shapes that have one kernel only (one
+    hidden layer, bc = 256, the generic path) ignore the hint; the group call refuses nothing when the flag rides on a
+    group of one."""
     rng = np.random.default_rng(11)
-    for (C, H, W, K, D, nl, bc, bs) in [(8, 70, 90, 5, 2, 2, 64, 512), (3, 33, 47, 4, 1, 1, 64, 256), (8, 40, 52, 5, 2, 2, 256, 512)]:
-        cfg = FeatCfg(False, False, 1.4, 12, True, True)
+    plain, embed = FeatCfg(False, False, 1.4, 12, True, True), FeatCfg(True, True, 1.4, 12, True, True)
+    for (C, H, W, K, D, nl, bc, bs, cfg) in [(8, 70, 90, 5, 2, 2, 64, 512, plain), (3, 33, 47, 4, 1, 1, 64, 256, plain),
+                                             (8, 40, 52, 5, 2, 2, 256, 512, plain), (8, 24, 20, 5, 2, 2, 64, 96, embed),
+                                             (8, 30, 31, 5, 2, 2, 64, 77, plain), (8, 9, 11, 5, 2, 2, 64, 8192, plain)]:
         img = synthetic_tile(5, C, H, W)
         msb, lab, mx = O.split_bits(img, K)
         F = cfg.feature_dim(C, D)
@@ -157,7 +164,8 @@ def test_alone_hint_changes_no_number(dev):
                     ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, e * steps, 1e-3, losses, path=path, ws=ws, alone=alone)
                 got.append([t.cpu().numpy().view(np.int32) for t in (p, m, v, losses)])
             for a, b in zip(*got):
-                assert np.array_equal(a, b), (bc, path)
+                assert np.array_equal(a, b), (bc, F, bs, path)
+            assert np.isfinite(got[0][0].view(np.float32)).all() and np.abs(got[0][1].view(np.float32)).max() > 0
 
 
 def test_mfma_train_rejects_unsupported_shapes(dev):
