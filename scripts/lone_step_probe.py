@@ -31,7 +31,9 @@ N = H * W
 nsteps = N // bs
 perm = torch.randperm(N, device=dev)
 ws = ops.TrainWorkspace(geom, net, bs, dev).prepare(img_d, msb_d, ops._lib.PATH_MFMA)
-stream = torch.cuda.current_stream()
+torch.cuda.synchronize()
+stream = torch.cuda.Stream(device=dev)     # (a stream of its own, as the product's fits have)
+torch.cuda.set_stream(stream)
 
 
 def epoch_ms(alone, mode):
