@@ -63,6 +63,8 @@ def parse():
                    help="skip the short legs of BASELINE.json configs[2] (bc = 256) and configs[4] (coordinates + embedding) "
                         "that a default one-GPU run of the headline configuration appends as `other_configs`")
     p.add_argument("--cpu-sample", type=int, default=512, help="side of the CPU-baseline crop")
+    p.add_argument("--cpu-full-epochs", type=int, default=10,
+                   help="epochs of form B (vectorised) measured on the WHOLE tile, scaled to the full recipe (0: skip)")
     p.add_argument("--cpu-epochs", type=int, default=1,
                    help="epochs of the recipe the CPU baseline runs on its crop (scaled to the full recipe)")
     a = p.parse_args()
@@ -141,6 +143,44 @@ def committed_profile(key, fits_per_launch):
     return prof, d
 
 
+def hbm_fields(a, seconds_per_tile, key, fits_per_launch):
+    """north_star asks for the fraction of the HBM roofline next to the matrix one.  Two figures per tile, both against
+    8 TB/s: the ALGORITHMIC bytes (16 B a pixel and pass -- one read of the uint16 source -- x 2 e passes, + 32 for
+    the split, + 32 for the decode = 384 B a pixel at e = 10: 1.61 GB per tile) and the bytes the hardware COUNTED
+    (profiles/pmc_summary.json: FETCH_SIZE / WRITE_SIZE per launch of every kernel of the path, separate --pmc passes,
+    x the launches a tile makes).  The second is ~90 x the first -- gradient slabs written through and read back, the
+    materialised row matrix gathered 832 B a row -- and is what the path really moves; timing-only builds price it at
+    <= 2.4 % of a tile: the path is matrix-bound, which is why `bound` says mfma."""
+    px = a.height * a.width
+    e = a.epochs
+    alg = (16 * 2 * e + 32 + 32) * px * (a.bands / 8.0)
+    out = {"hbm_algorithmic_bytes_per_tile": int(alg), "hbm_algorithmic_GBps": round(alg / seconds_per_tile / 1e9, 1),
+           "hbm_frac_algorithmic": round(alg / seconds_per_tile / 8e12, 5), "hbm_peak_GBps": 8000.0}
+    prof, whole = committed_profile(key if px == 2048 * 2048 and a.bands == 8 else None, fits_per_launch)
+    if not prof:
+        out["counted_bytes_per_tile"] = None
+        return out
+    steps = e * ((px + a.bs - 1) // a.bs)
+    per_fit = 1.0 / max(fits_per_launch, 1)
+    parts = {}
+    for name, launches in (("train", steps * per_fit), ("dw", steps), ("reduce", steps * per_fit), ("apply_eval", e if e > 1 else 0),
+                           ("apply_decode", 1), ("build_rows", 1)):
+        b = prof.get(name, {}).get("hbm_bytes_per_launch")
+        if name == "apply_decode" and b is None:     # (the pair configuration is counted on fits only: the decode pass of the one-fit run)
+            b = whole.get("configs", {}).get(key, {}).get("apply_decode", {}).get("hbm_bytes_per_launch")
+        if name == "build_rows" and b is None:       # (not in the counter passes: its algorithmic bytes -- the row matrix written once, both planes read)
+            b = px * (832 if key != "embed" else 1088) + 2 * a.bands * px * 2 if key != "bc256" else px * 832 + 2 * a.bands * px * 2
+        if b is not None and launches:
+            parts[name] = int(b * launches)
+    total = sum(parts.values())
+    out.update({"counted_bytes_per_tile": total, "counted_bytes_by_kernel": parts,
+                "counted_TBps": round(total / seconds_per_tile / 1e12, 3), "counted_frac_of_hbm_peak": round(total / seconds_per_tile / 8e12, 4),
+                "counted_over_algorithmic": round(total / alg, 1),
+                "counted_source": "profiles/pmc_summary.json x launches per tile (per-launch bytes of a launch of "
+                                  f"{fits_per_launch} fit(s), shared between them); kernels without a counter pass at their algorithmic bytes"})
+    return out
+
+
 def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single=True):
     """Live HIP-event timing, on the launch stream, right after the timed region (same process, same tile).
     Dominant kernel = the fused training step (5120 launches per tile, ~55 % of the GPU time of a fit).
@@ -178,14 +218,15 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
     if per_launch is None:
         per_launch = tiles_per_launch(a, ops, path)
 
-    def probe(count):
+    def probe(count, alone=False):
         """per step, in ms, for `count` fits per launch: (whole step, training launch alone = mode 3, one more training
-        launch = mode 2 - mode 0, one more reduce launch = mode 1 - mode 0)"""
+        launch = mode 2 - mode 0, one more reduce launch = mode 1 - mode 0).  alone: with the LBDRN_TRAIN_ALONE hint, as
+        codec.fit_device steps a fit that has the device to itself (k_train_split where the shape has it)"""
         perms = [torch.randperm(N, device=img_d.device) for _ in range(count)]
         st = [(p.clone(), torch.zeros_like(p), torch.zeros_like(p)) for _ in range(count)]
         wss = [ops.TrainWorkspace(geom, net, a.bs, img_d.device).prepare(img_d, fit.msb, path) for _ in range(count)]
         if count == 1:
-            run = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perms[0], a.bs, *st[0], 0, 1e-6, None, path, wss[0])
+            run = lambda: ops.train_epoch(geom, net, img_d, fit.msb, perms[0], a.bs, *st[0], 0, 1e-6, None, path, wss[0], alone=alone)
         else:
             run = lambda: ops.train_epoch_group([geom] * count, net, [img_d] * count, [fit.msb] * count, perms, a.bs,
                                                 [x[0] for x in st], [x[1] for x in st], [x[2] for x in st], 0, 1e-6,
@@ -245,15 +286,23 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
                               "kernel); unaccounted_us the rest of the step.  rocprof_kernel_us: the committed rocprofv3 "
                               "--kernel-trace average of the same launch sequence (profiles/, see rocprof_source); frac = "
                               "min(frac_live, frac_rocprof)"})
-        if with_single and per_launch > 1:   # the launch of a fit alone (what a single tile runs), same method
-            s1, o1, k1, r1 = probe(1)
-            a1 = step * B / (o1 * 1e-3) / 1e12
-            out["single_fit_launch"] = {"kernel_us": round(o1 * 1e3, 2), "marginal_us": round(k1 * 1e3, 2),
-                                        "reduce_adam_us": round(r1 * 1e3, 2),
-                                        "unaccounted_us": round((s1 - k1 - r1) * 1e3, 2), "train_step_pair_us": round(s1 * 1e3, 2),
-                                        "flop_per_launch": step * B, "cus_occupied": min(256, nwg), "achieved": round(a1, 3),
-                                        "frac": round(a1 / peak, 4),
-                                        "frac_of_occupied_cus": round(a1 / (peak * min(256, nwg) / 256.0), 4)}
+        if with_single and per_launch > 1:   # the launches of a fit alone (what a single tile runs), same method
+            # Most of a lone fit's steps carry the LBDRN_TRAIN_ALONE hint: 2 x nwg workgroups of 32 rows on every CU
+            # (k_train_split, csrc/train_split.inc; two gradient slabs per 64-row group) -- the same numbers bit for bit as
+            # the half-chip launch, which the fit still uses beside its background evaluation pass (`half_chip_launch`)
+            def rec(s1, o1, k1, r1, cus):
+                a1 = step * B / (o1 * 1e-3) / 1e12
+                return {"kernel_us": round(o1 * 1e3, 2), "marginal_us": round(k1 * 1e3, 2), "reduce_adam_us": round(r1 * 1e3, 2),
+                        "unaccounted_us": round((s1 - k1 - r1) * 1e3, 2), "train_step_pair_us": round(s1 * 1e3, 2),
+                        "flop_per_launch": step * B, "cus_occupied": cus, "achieved": round(a1, 3), "frac": round(a1 / peak, 4),
+                        "frac_of_occupied_cus": round(a1 / (peak * cus / 256.0), 4)}
+            half = rec(*probe(1), min(256, nwg))
+            full = rec(*probe(1, alone=True), min(256, 2 * nwg))
+            split_runs = full["kernel_us"] < 0.9 * half["kernel_us"]      # (shapes without k_train_split ignore the hint)
+            out["single_fit_launch"] = dict(full if split_runs else half,
+                                            kernel=(f"k_train_split: {2 * nwg} workgroups of 32 rows, units halved between two waves, every CU"
+                                                    if split_runs else f"k_train_stream: {nwg} workgroups of 64 rows"),
+                                            half_chip_launch=half if split_runs else None)
     else:  # shape without a fused train kernel: the generic step is many launches
         t_k = t_step
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
@@ -331,18 +380,40 @@ def cpu_baseline(a):
         t_dec = time.time() - t0
         return side * side / (t_enc + t_dec) / 1e6, t_enc, t_dec, t_call
 
+    full = None
     try:
         sweep = {}
         for th in sorted({t for t in (8, 16, 32, 64, all_threads) if t <= all_threads}):
             sweep[th] = run(False, th)
         best_th = max(sweep, key=lambda th: sweep[th][0])
         form_a = run(True, best_th)
+        if a.cpu_full_epochs > 0 and side < min(a.height, a.width):
+            # form B once more on the WHOLE tile, nothing scaled but (optionally) the epoch count: ~30 s at the headline shape
+            torch.set_num_threads(best_th)
+            torch.manual_seed(SEED)
+            whole = synthetic_tile(0, a.bands, a.height, a.width)
+            epf = max(2, min(a.cpu_full_epochs, a.epochs)) if a.epochs > 1 else 1
+            t0 = time.time()
+            r = TP.fit(whole, a.K, a.D, a.bc, a.nl, a.lr, a.bs, epf, cfg=ocfg, faithful=False, num_workers=0)
+            t_call = time.time() - t0
+            t_enc = (t_call - r["seconds"]) + r["seconds"] * (a.epochs / epf)
+            t0 = time.time()
+            TP.apply(r["msb"], r["params"], a.K, a.D, a.bc, a.nl, cfg=ocfg)
+            t_dec = time.time() - t0
+            full = {"mpixels_per_s": round(a.height * a.width / (t_enc + t_dec) / 1e6, 6), "threads": best_th, "epochs_measured": epf,
+                    "measured_s": round(t_call + t_dec, 1), "encode_s": round(t_enc, 1), "decode_s": round(t_dec, 1),
+                    "sample": f"the whole {a.bands} x {a.height} x {a.width} tile, {epf} of {a.epochs} epochs measured"}
+            del whole, r
     finally:
         torch.set_num_threads(all_threads)
     fb = sweep[best_th]
     return {"value": round(form_a[0], 6), "unit": "Mpixels/s", "cores": best_th,
             "host_cpus": os.cpu_count(), "kind": "port", "loader_workers": workers,
+            "value_note": "form A on the crop, scaled linearly to the tile: an UPPER bound of what this CPU does on the whole tile "
+                          "(the reference's concatenating metric is quadratic in the number of minibatches: the crop understates "
+                          "its cost); form B was also run on the whole tile (vectorised_form_B_full_tile)",
             "vectorised_form_B": round(fb[0], 6),
+            "vectorised_form_B_full_tile": full,
             "form_B_by_threads": {str(th): round(v[0], 6) for th, v in sweep.items()},
             "sample": f"{side}x{side}x{a.bands} crop of tile 0 ({(side * side + a.bs - 1) // a.bs} minibatches per pass), "
                       f"{ep} of {a.epochs} epochs measured (bs={a.bs}; every epoch = one training pass + one evaluation "
@@ -642,6 +713,7 @@ def main():
         out["roofline"]["end_to_end_tflops"] = round(tile_flop * a.steps * world / elapsed / 1e12, 3)
         out["roofline"]["end_to_end_frac"] = round(tile_flop * a.steps / elapsed / 1e12 / 157.3, 4)
         out["roofline"]["single_tile_end_to_end_frac"] = round(tile_flop / (single["ms"] * 1e-3) / 1e12 / 157.3, 4)
+        out["roofline"].update(hbm_fields(a, elapsed / a.steps, config_key(a), out["config"]["tiles_per_launch"]))
         del single, lone, lone_rec
         if world == 1 and not a.no_other_configs and config_key(a) == "bc64" and a.height == 2048 and a.width == 2048 \
                 and a.path == "auto":

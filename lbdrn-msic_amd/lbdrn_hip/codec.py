@@ -128,9 +128,54 @@ def overlap_evaluation(dev, alone):
     env = os.environ.get("LBDRN_OVERLAP_EVAL")
     if env in ("0", "1"):
         return env == "1"
-    if not alone:
+    if not alone or device_shared():
         return False
     return alone_streams_fit_queues()
+
+
+def device_shared():
+    """LBDRN_DEVICE_SHARED=1: other PROCESSES fit on this GPU (run.sh / sweep.py with PER_GPU > 1 export it).  A process
+    cannot see its neighbour's fits, so the caller says so: its fits then never claim the whole device -- no LBDRN_TRAIN_ALONE
+    hint (the every-CU training launch would take turns with the neighbour's), evaluation passes in the chain."""
+    return os.environ.get("LBDRN_DEVICE_SHARED", "0") not in ("", "0")
+
+
+def fit_bytes(C, H, W, K, D, base_channel, num_layers, batch_size, epochs, cfg=None):
+    """Device bytes one fit of this shape holds while it runs (fit_device): the training workspace -- dominated by the
+    [N][F + C] row matrix, 832 B a pixel at the headline shape --, the permutations of all epochs and their scratch, the
+    image, its MSB plane and the decoded raster, the evaluation workspace, snapshots.  What fit_many divides the free
+    memory by."""
+    cfg = cfg or FeatCfg.from_constants()
+    N = H * W
+    g = ops._lib.Geom(C, H, W, K, D, 1, int(cfg.use_colors), int(cfg.relative), int(cfg.P), 0, None, None)
+    net = ops.make_net(cfg.feature_dim(C, D), base_channel, C, num_layers)
+    L = ops.lib()
+    import ctypes
+    train = int(L.lbdrn_train_workspace(ctypes.byref(g), ctypes.byref(net), batch_size))
+    apply_ws = int(L.lbdrn_apply_workspace(ctypes.byref(g), ctypes.byref(net)))
+    perms = epochs * N * 8 + int(L.lbdrn_randperm_workspace(N, min(32, max(epochs - 1, 1))))
+    planes = 3 * C * N * 2                       # image, MSB plane, reconstruction
+    return train + apply_ws + perms + planes + (epochs + 4) * int(ops.param_count(net)) * 4 + (64 << 20)
+
+
+def memory_limited_in_flight(images, wanted, K, D, base_channel, num_layers, batch_size, epochs, cfg=None):
+    """How many of `images` may progress together: `wanted`, or fewer where the device's free memory (plus what this
+    process's allocator already holds in reserve) does not hold that many of the largest fit at 85 %.  One 8 x 2048^2 tile is
+    3.9 GB, a 6000 x 6000 x 8 scene (the reference's GF6-WFI size) 34 GB; a fit that does not fit at all raises
+    with the numbers (split the image: -sr)."""
+    if not images:
+        return wanted
+    dev = images[0].device
+    need = max(fit_bytes(*tuple(t.shape), K, D, base_channel, num_layers, batch_size, epochs, cfg) for t in images)
+    free, total = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)     # cached blocks are this process's to reuse
+    if device_shared():
+        free //= 2                                                                  # (the neighbour process sizes itself the same way)
+    fits = int(0.85 * free // need)
+    if fits < 1:
+        raise ops._lib.LbdrnError(f"one fit of this shape holds {need / 2**30:.1f} GiB on the device, {free / 2**30:.1f} GiB are free "
+                                  f"(of {total / 2**30:.0f}): split the image (-sr)")
+    return max(1, min(wanted, fits))
 
 
 def background_steps(steps_per_epoch):
@@ -170,6 +215,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     dev = img_d.device
     C, H, W = img_d.shape
     N = H * W
+    alone = alone and not device_shared()
     msb_d, msb_max = ops.split_bits(img_d, K)            # a1
     geom = ops.FeatureGeometry(C, H, W, K, D, msb_max, cfg, dev)
     if N >= GPU_RANDPERM_MAX:
@@ -356,6 +402,7 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     caller made in tile order).  Returns after all streams have been joined to the caller's current stream."""
     if in_flight is None:
         in_flight = 4
+    in_flight = memory_limited_in_flight(images, in_flight, K, D, base_channel, num_layers, batch_size, epochs, cfg)
     if group is None:
         group = int(os.environ.get("LBDRN_FIT_GROUP", "0"))
         if group == 0:

@@ -706,3 +706,47 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert str(c["cores"]) in c["form_B_by_threads"] and c["vectorised_form_B"] == max(c["form_B_by_threads"].values())
+
+
+def test_the_reference_scene_size_through_the_clis(dev, tmp_path):
+    """the reference's real image shape, once -- an 8-band 6000 x 6000 uint16 scene (the GF6-WFI
+    scenes of its tables; ref encode.py:228-262, LBDRNdataset.py:46-68) through encode.py /
+    decode.py with -sr 1 (one 36 M-pixel fit: 30 GB of rows, lbdrn_randperm beyond its partitioned path's 2048^2) and
+    -sr 3 (nine 2000 x 2000 tiles, fits in flight sized against the free memory).  The high bits come back exact, the
+    payload sizes agree with each other, the device high-water mark stays under codec.fit_bytes' estimate, and the
+    permutation of 36 M elements is a permutation.  Three epochs keep the test short; scripts/scene_timing.py is the
+    ten-epoch record (profiles/r05_scene_6000x6000x8.jsonl: 1.7 s to encode, 0.5 s to decode, 31.8 GiB)."""
+    import encode as enc_mod
+    import decode as dec_mod
+    free, total = torch.cuda.mem_get_info(dev)
+    side, C, K, epochs = 6000, 8, 5, 3
+    need = codec.fit_bytes(C, side, side, K, 2, 64, 2, 8192, epochs)
+    if free < 1.2 * need:
+        pytest.skip(f"needs {need / 2**30:.0f} GiB of free device memory")
+    img = synthetic_tile(7, C, side, side)
+    src = str(tmp_path / "scene.npy")
+    raster_io.write_raster(src, img)
+    n = side * side
+    perm = ops.randperm([19920517], n, dev)[0]
+    assert int(perm.min()) == 0 and int(perm.max()) == n - 1 and torch.equal(torch.sort(perm).values, torch.arange(n, device=dev))
+    del perm
+    sizes = {}
+    for sr in (1, 3):
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats(dev)
+        out = tmp_path / f"out{sr}"
+        assert enc_mod.main(["-i", src, "-o", str(out), "-sr", str(sr), "-e", str(epochs)]) in (0, None)
+        sub = out / f"scene_r{sr}_K{K}_bc64_nl2_D2_prec16_lr0.001_bs8192_e{epochs}"
+        assert dec_mod.main(["-i", str(sub / "scene.bin")]) in (0, None)
+        peak = torch.cuda.max_memory_allocated(dev)
+        tile = side // sr + side % sr
+        in_flight = 1 if sr == 1 else 4
+        assert peak <= in_flight * codec.fit_bytes(C, tile, tile, K, 2, 64, 2, 8192, epochs) + 3 * img.nbytes, (sr, peak)
+        rec = raster_io.read_raster(str(sub / "scene_recon.tif"))
+        assert rec.shape == img.shape and np.array_equal(rec >> K, img >> K), sr
+        mse = float(np.mean((img.astype(np.float32) - rec.astype(np.float32)) ** 2))
+        assert mse < 31.0 ** 2 / 3, (sr, mse)                      # (better than predicting mid-range; a fit that learned: ~81)
+        sizes[sr] = os.path.getsize(sub / "scene.bin")
+        os.remove(sub / "scene_recon.tif")
+        del rec
+    assert abs(sizes[1] - sizes[3]) < 0.02 * sizes[1], sizes       # (the MSB planes dominate; nine small networks instead of one)

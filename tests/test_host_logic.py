@@ -406,3 +406,35 @@ def test_mt19937_jump_polynomials_reproduce_the_sequence():
         for k in (1, 2, 311, 623):
             assert np.bitwise_xor.reduce(x[idx + k]) == x[s * seg + k], (s, k)
         assert np.bitwise_xor.reduce(x[idx]) >> 31 == x[s * seg] >> 31   # word 0 of a state window: its top bit is all the recurrence reads
+
+
+def test_fits_in_flight_are_sized_against_the_free_memory(monkeypatch):
+    """codec.fit_many no longer takes `in_flight` on faith: the count is cut to what 85 % of the
+    free device memory holds of the largest fit; a fit that does not fit at all raises with the numbers; a process that
+    shares its GPU (run.sh with PER_GPU > 1: LBDRN_DEVICE_SHARED) sizes itself against half."""
+    import torch
+    from lbdrn_hip import codec, ops
+
+    class T:                                      # (only .shape and .device are looked at)
+        def __init__(self, *shape):
+            self.shape, self.device = shape, "cuda:0"
+    one = codec.fit_bytes(8, 2048, 2048, 5, 2, 64, 2, 8192, 10)
+    big = codec.fit_bytes(8, 6000, 6000, 5, 2, 64, 2, 8192, 10)
+    assert 3.9 * 2**30 < one < 5.5 * 2**30 and 31 * 2**30 < big < 36 * 2**30     # row matrix 832 B a pixel + permutations + planes
+    assert codec.fit_bytes(8, 2048, 2048, 5, 2, 256, 2, 8192, 10) > one - 2**30  # (the wide step: 848 B rows, hand-over buffers)
+    monkeypatch.delenv("LBDRN_DEVICE_SHARED", raising=False)
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda dev=None: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda dev=None: 0)
+    args = (5, 2, 64, 2, 8192, 10)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (280 << 30, 288 << 30))
+    assert codec.memory_limited_in_flight([T(8, 2048, 2048)] * 8, 4, *args) == 4
+    assert codec.memory_limited_in_flight([T(8, 6000, 6000)] * 4, 4, *args) == 4          # 4 x 34 GiB fit on a 288 GB part
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (100 << 30, 288 << 30))
+    assert codec.memory_limited_in_flight([T(8, 6000, 6000)] * 4, 4, *args) == 2
+    assert codec.memory_limited_in_flight([T(8, 2000, 2000), T(8, 6000, 6000)], 4, *args) == 2   # the largest fit decides
+    monkeypatch.setenv("LBDRN_DEVICE_SHARED", "1")
+    assert codec.memory_limited_in_flight([T(8, 6000, 6000)] * 4, 4, *args) == 1
+    assert codec.device_shared()
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (20 << 30, 288 << 30))
+    with pytest.raises(ops._lib.LbdrnError, match="split the image"):
+        codec.memory_limited_in_flight([T(8, 6000, 6000)], 4, *args)
