@@ -299,6 +299,12 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
             half = rec(*probe(1), min(256, nwg))
             full = rec(*probe(1, alone=True), min(256, 2 * nwg))
             split_runs = full["kernel_us"] < 0.9 * half["kernel_us"]      # (shapes without k_train_split ignore the hint)
+            skt = whole.get("configs", {}).get(key, {}).get("kernel_trace", {}) if (split_runs and key) else {}
+            if skt.get("split_avg_us"):   # the committed rocprofv3 --kernel-trace average of the every-CU launch, as for the headline launch
+                r_ach = step * B / (float(skt["split_avg_us"]) * 1e-6) / 1e12
+                full.update({"rocprof_kernel_us": skt["split_avg_us"], "rocprof_kernel_min_us": skt.get("split_min_us"),
+                             "rocprof_source": skt.get("source"), "frac_live": full["frac"], "frac_rocprof": round(r_ach / peak, 4),
+                             "frac": round(min(full["achieved"], r_ach) / peak, 4)})
             out["single_fit_launch"] = dict(full if split_runs else half,
                                             kernel=(f"k_train_split: {2 * nwg} workgroups of 32 rows, units halved between two waves, every CU"
                                                     if split_runs else f"k_train_stream: {nwg} workgroups of 64 rows"),

@@ -29,6 +29,9 @@ STAMPS = {
     "pair": ("two fits per launch (2 x 128 workgroups), alone on the device", ["scripts/stamp_probe_group.py", "2"]),
     "bc256": ("bc = 256, one fit per launch, alone on the device", ["scripts/stamp_probe_wide.py", "2048"]),
     "embed": ("USE_COORDINATES + EMBEDDING, one fit per launch, alone", ["scripts/stamp_probe_group.py", "1", "embed"]),
+    # the every-CU launch of a fit that has the device to itself (k_train_split: 256 workgroups of 32 rows), real epochs
+    "split": ("one fit per launch on every CU (LBDRN_TRAIN_ALONE), alone on the device", ["scripts/lone_step_probe.py", "3", "--only", "split", "--modes", "0"]),
+    "split_embed": ("USE_COORDINATES + EMBEDDING, every-CU launch, alone", ["scripts/lone_step_probe.py", "3", "--embed", "--only", "split", "--modes", "0"]),
 }
 TIMELINE = {
     "bc64": ("one chain of single-fit launches, alone on the device", ["scripts/stamp_probe_inflight.py", "1", "3", "8", "2", "1"]),
@@ -36,6 +39,8 @@ TIMELINE = {
     "pair": ("one chain of pair launches, alone on the device", ["scripts/stamp_probe_inflight.py", "2", "3", "8", "2", "2"]),
     "pair_two_chains": ("two chains of pair launches in flight (the timed region of bench.py)",
                         ["scripts/stamp_probe_inflight.py", "4", "3", "8", "2", "2"]),
+    "split": ("one chain of every-CU launches (k_train_split) and their reduce launches over slab pairs, alone on the device",
+              ["scripts/lone_step_probe.py", "3", "--only", "split", "--modes", "0"]),
 }
 
 
@@ -92,7 +97,7 @@ def collect_timeline(name, what, cmd):
     res = {"config": name, "what": what, "command": "LBDRN_HIP_LIB=lbdrn-msic_amd/liblbdrn_hip_timeline.so python3 " + " ".join(cmd),
            "rc": rc, "epochs_printed": len(lines)}
     if lines:
-        n_chains = max(1, int(cmd[1]) // max(1, int(cmd[5]) if len(cmd) > 5 else 1))
+        n_chains = 1 if "lone_step_probe" in cmd[0] else max(1, int(cmd[1]) // max(1, int(cmd[5]) if len(cmd) > 5 else 1))
         use = lines[n_chains:] or lines    # the first epoch of every chain starts behind the permutation pipeline
         rows = [pieces(l, "steps:") for l in use]
         names = ["train_first_wave_start_to_last_store_us", "gap_to_reduce_start_us", "reduce_us", "gap_to_next_train_us", "step_us"]

@@ -2,7 +2,8 @@
 k_train_stream (128 workgroups of 64 rows; alone=False) and k_train_split (256 workgroups of 32 rows; alone=True).
 HIP events around whole 512-step epochs on the full 8 x 2048^2 tile, lbdrn_train_profile_mode as in bench.py:
 mode 0 = the real epoch, 3 = training launches alone (cold rows), 2 = training launch doubled, 1 = reduce doubled.
-usage: lone_step_probe.py [repeats=3] [--embed] [-bc N]"""
+usage: lone_step_probe.py [repeats=3] [--embed] [-bc N] [--only stream|split] [--modes 0,3,2,1]
+(--only / --modes: what scripts/collect_inkernel.py runs under the stamped and timeline builds -- one kernel, real epochs only)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lbdrn-msic_amd"))
@@ -15,6 +16,9 @@ from lbdrn_hip.synth import synthetic_tile
 reps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 3
 embed = "--embed" in sys.argv
 bc = int(sys.argv[sys.argv.index("-bc") + 1]) if "-bc" in sys.argv else 64
+only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+modes = tuple(int(x) for x in sys.argv[sys.argv.index("--modes") + 1].split(",")) if "--modes" in sys.argv else (0, 3, 2, 1)
+kinds = [k for k in (False, True) if only is None or (only == "split") == k]
 dev = torch.device("cuda:0")
 C, H, W, K, D, nl, bs = 8, 2048, 2048, 5, 2, 2, 8192
 cfg = FeatCfg(True, True, 1.4, 12, True, True) if embed else FeatCfg(False, False, 1.4, 12, True, True)
@@ -51,18 +55,21 @@ def epoch_ms(alone, mode):
         ops.train_profile_mode(0)
 
 
-for alone in (False, True):
+for alone in kinds:
     epoch_ms(alone, 0)
 res = {}
 for r in range(reps):
-    for alone in (False, True):
-        for mode in (0, 3, 2, 1):
+    for alone in kinds:
+        for mode in modes:
             t, p = epoch_ms(alone, mode)
             res.setdefault((alone, mode), []).append(t)
             if mode == 0:
                 res.setdefault(("p", alone), p)
-same = torch.equal(res[("p", False)].view(torch.int32), res[("p", True)].view(torch.int32))
-for alone in (False, True):
+same = torch.equal(res[("p", False)].view(torch.int32), res[("p", True)].view(torch.int32)) if len(kinds) == 2 else None
+for alone in kinds:
+    if modes != (0, 3, 2, 1):
+        print(f"{'k_train_split (alone)' if alone else 'k_train_stream       '}: step {min(res[(alone, 0)]) / nsteps * 1e3:.2f} us")
+        continue
     t0, t3, t2, t1 = (min(res[(alone, m)]) / nsteps * 1e3 for m in (0, 3, 2, 1))
     print(f"{'k_train_split (alone)' if alone else 'k_train_stream       '}: step {t0:.2f} us | training launch alone {t3:.2f} | one more training launch "
           f"{t2 - t0:.2f} | one more reduce launch {t1 - t0:.2f} | rest {t0 - (t2 - t0) - (t1 - t0):.2f}   (epoch {min(res[(alone, 0)]):.2f} ms; all: "

@@ -35,16 +35,17 @@ for f in sorted(os.listdir(src)):
     if f.endswith((".csv", ".json")) and not f.startswith("."):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 # (apply_eval: the evaluation pass as a fit runs it -- MODE_EVAL_FAST = 2; the canonical MODE_EVAL = 1 pass where a run used it)
-KERNELS = {"bc64": {"train": "k_train_stream<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+KERNELS = {"bc64": {"train": "k_train_stream<48", "train_split": "k_train_split<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>",
+                    "build_rows": "k_build_rows_tiled"},
            "bc256": {"train": "k_train_half", "dw": "k_dw_wide", "reduce": "k_reduce_adam", "apply_eval": "k_apply_wide<16, 2, 2>", "apply_decode": "k_apply_wide<16, 2, 0>"},
-           "embed": {"train": "k_train_stream<64", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+           "embed": {"train": "k_train_stream<64", "train_split": "k_train_split<64", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
            # the launches of a PAIR of bc64 fits stepping side by side (scripts/prof_pair.py): 2 x 128 workgroups, every CU
            "pair": {"train": "k_train_stream<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>"}}
 # MI355X_MICROARCH.md, HBM: "on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B per
 # lane, global_load and buffer_load ... lds alike)" -- so the doubling applies to the kernels whose fetches ARE such reads
 # (rows by LDS-DMA, fragments / weights / slabs as 16-byte loads) and NOT to the apply kernels, which fetch two uint16 planes
 # in 2- and 4-byte pieces: their un-doubled 134.0 MB per pass is exactly img + msb
-FETCH_DOUBLED = ("k_train_stream", "k_train_wide", "k_train_half", "k_reduce_adam", "k_dw_wide", "k_train_mfma")
+FETCH_DOUBLED = ("k_train_stream", "k_train_split", "k_train_wide", "k_train_half", "k_reduce_adam", "k_dw_wide", "k_train_mfma")
 out = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_* in separate passes of scripts/prof_fit.py per "
                  f"configuration (one fit at a time: scripts/profile_round.sh {tag}); per-kernel means in profiles/{tag}_pmc_*.csv and "
                  f"profiles/{tag}_sq_*.csv.  FETCH_SIZE is doubled for the kernels whose fetches are 16-byte-per-lane streaming reads "
@@ -98,6 +99,8 @@ for cfg, kernels in KERNELS.items():
             e.update(mfma_busy_cycles_per_launch=busy[1], mfma_insts_per_launch=insts[1] if insts else None,
                      duration_us_in_counter_pass=round(busy[2] / 1e3, 2),
                      mfma_busy_frac_whole_chip=round(busy[1] / (1024 * dur_cycles), 4))     # 256 CUs x 4 SIMDs
+            if key == "train_split":   # 256 workgroups of four compute waves: every SIMD of the chip
+                e["mfma_busy_frac_occupied_simds"] = e["mfma_busy_frac_whole_chip"]
             if key == "train":   # 128 workgroups of one fit (pair, and the 256 32-row workgroups of bc256: every CU), one compute
                                  # wave per SIMD: 512 (1024) of the chip's 1024 SIMDs
                 e["mfma_busy_frac_occupied_simds"] = round((1 if cfg in ("pair", "bc256") else 2) * e["mfma_busy_frac_whole_chip"], 4)
@@ -114,8 +117,8 @@ for cfg, kernels in KERNELS.items():
     if cout:
         cout["algorithmic_bytes_per_train_launch"] = 8192 * 16 * (2 if cfg == "pair" else 1)
         out["configs"][cfg] = cout
-for cfg, csv_name in TRACE.items():
-    t = trace_avg(csv_name, KERNELS.get(cfg, KERNELS["embed"])["train"])
+for cfg, csv_name in list(TRACE.items()) + [("split", None), ("split_embed", None)]:
+    t = trace_avg(csv_name, KERNELS.get(cfg, KERNELS["embed"])["train"]) if csv_name else None
     cout = out["configs"].setdefault(cfg, {})
     if t:
         cout["kernel_trace"] = {"train_avg_us": t[0], "train_min_us": t[1], "train_calls": t[2], "kernel": t[3],
@@ -126,6 +129,9 @@ for cfg, csv_name in TRACE.items():
         d = trace_avg(csv_name, "k_dw_wide") if cfg == "bc256" else None
         if d:
             cout["kernel_trace"].update(dw_avg_us=d[0], dw_min_us=d[1])
+        sp = trace_avg(csv_name, KERNELS.get(cfg, {}).get("train_split", "k_train_split<none"))
+        if sp:   # the every-CU launch of a lone fit (most of the steps of such a trace; the rest go out on the half-chip launch above)
+            cout["kernel_trace"].update(split_avg_us=sp[0], split_min_us=sp[1], split_calls=sp[2], split_kernel=sp[3])
     for kind in ("timeline", "stamps"):
         j = load_json(f"{kind}_{cfg}.json")
         if j and (j.get("per_step_us") or j.get("mean_cycles_per_phase")):
