@@ -166,6 +166,53 @@ def test_train_fuzz_mfma_matches_generic(dev):
     assert done >= 6, done
 
 
+def test_two_training_kernels_one_set_of_bits_fuzz(dev):
+    """k_train_stream (64-row workgroups, half the chip: the step with company) and k_train_split (32-row workgroups, units
+    halved between two waves, every CU: the step of a fit alone, LBDRN_TRAIN_ALONE) share one summation tree
+    (csrc/train_split.inc): on random images of the two shapes that have both -- F = 200 and the embedding's F = 250 at
+    bc = 64, two hidden layers --, random K, batch sizes that leave ragged groups, one-row tails and minibatches shorter than a
+    workgroup, two epochs of each leave the same parameters, Adam moments and losses bit for bit, and they train."""
+    rng = np.random.default_rng(20260105)
+    MFMA = ops._lib.PATH_MFMA
+    shapes = [FeatCfg(False, False, 1.4, 12, True, True), FeatCfg(True, True, 1.4, 12, True, True)]
+    tails = 0
+    for it in range(10 * SOAK):
+        cfg = shapes[it % 2]
+        C, D, bc, nl = 8, 2, 64, 2
+        H, W, K = int(rng.integers(5, 40)), int(rng.integers(5, 60)), int(rng.integers(1, 8))
+        bs = int(rng.choice([33, 64, 65, 100, 257, 1000, H * W - 1, H * W + 7]))
+        bs = max(bs, 2)
+        if it < 2:                                     # (a one-row tail for either shape, whatever the generator drew)
+            H, W, bs = (5, 13, 64) if it == 0 else (7, 9, 31)
+        img = rng.integers(0, 1 << int(rng.integers(K + 2, 15)), (C, H, W)).astype(np.uint16)
+        msb = img >> K
+        mx = int(msb.max())
+        if mx == 0:
+            continue
+        F = cfg.feature_dim(C, D)
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(F, bc, C, nl)
+        p0 = _params(rng, F, bc, C, nl, 1.0)
+        perm = torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev)
+        img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+        steps = (H * W + bs - 1) // bs
+        tails += (H * W) % bs == 1
+        got = []
+        for alone in (False, True):
+            p = torch.from_numpy(p0.copy()).to(dev)
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            losses = torch.zeros(steps, dtype=torch.float32, device=dev)
+            ws = ops.TrainWorkspace(geom, net, bs, dev).prepare(img_d, msb_d, MFMA)
+            for e in range(2):
+                ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, e * steps, 1e-3, losses, path=MFMA, ws=ws, alone=alone)
+            got.append([t.cpu().numpy() for t in (p, m, v, losses)])
+        tag = (it, F, H, W, K, bs)
+        for a, b in zip(*got):
+            assert np.array_equal(a.view(np.int32), b.view(np.int32)), tag
+        assert np.isfinite(got[0][0]).all() and np.abs(got[0][1]).max() > 0, tag
+    assert tails >= 2     # (a minibatch of ONE row: that step goes out on k_train_stream even for a fit alone)
+
+
 def test_wide_train_fuzz_split_step_matches_generic(dev):
     """The three launches of the bc >= 128 step (k_train_half -> k_dw_wide -> k_reduce_adam) on random shapes: bands 1..16,
     D 0..3, every constants.py switch, bc 128 / 256, one and two hidden layers, minibatch sizes that leave half-filled
