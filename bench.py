@@ -725,7 +725,8 @@ def main():
                 and a.path == "auto":
             # BASELINE.json configs[2] and configs[4], a short leg each in the same call (the headline above is unchanged)
             out["other_configs"] = {
-                "bc256": side_leg(codec, ops, tiles, a, path, bc=256, in_flight=3, steps=6, warmup=3,   # (2: 352, 3: 343, 4: 386, 6: 345 ms per tile)
+                "bc256": side_leg(codec, ops, tiles, a, path, bc=256, in_flight=codec.default_in_flight(a.bands, a.height, a.width, a.K, a.D, 256, a.nl),
+                                  steps=6, warmup=3,   # (codec.default_in_flight: 3 chains at bc >= 128 -- 2: 352, 3: 343, 4: 386, 6: 345 ms per tile)
                                   label="BASELINE.json configs[2]: the same tile, bc = 256 (k_train_half + k_dw_wide / k_apply_wide)"),
                 "embed": side_leg(codec, ops, tiles, a, path, coords_embedding=True, in_flight=4, steps=8, warmup=4,
                                   label="BASELINE.json configs[4]: USE_COORDINATES + EMBEDDING (F = 250)"),

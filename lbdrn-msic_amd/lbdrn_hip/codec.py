@@ -158,6 +158,24 @@ def fit_bytes(C, H, W, K, D, base_channel, num_layers, batch_size, epochs, cfg=N
     return train + apply_ws + perms + planes + (epochs + 4) * int(ops.param_count(net)) * 4 + (64 << 20)
 
 
+def default_in_flight(C, H, W, K, D, base_channel, num_layers, cfg=None, path=None):
+    """How many fits of this shape progress together on one GPU when the caller does not say (fit_many, the CLIs): as many
+    chains as can each have a launch resident, one more would only queue.
+    * the fused bc = 64 step takes pairs of fits per launch (2 x 128 workgroups of 147 KB of LDS = every CU, one workgroup
+      each): two such chains alternate -- one trains while the other reduces / evaluates -- and saturate the chip: 4 fits;
+    * the bc >= 128 step is three launches that all want every CU: k_train_half (72 KB of LDS, 194 registers: two
+      workgroups per CU), k_dw_wide (66 KB, 284 registers: one wave per SIMD), k_reduce_adam / the evaluation pass.  Three
+      chains can each have one of them resident; a fourth chain's forward/backward workgroups queue behind the resident pair
+      and which chains meet decides the time (343 or 386 ms per tile: DESIGN 4.5): 3 fits;
+    * the generic path is many small launches per step: 4."""
+    cfg = cfg or FeatCfg.from_constants()
+    if path == ops._lib.PATH_GENERIC:
+        return 4
+    if base_channel >= 128:
+        return 3
+    return 4
+
+
 def memory_limited_in_flight(images, wanted, K, D, base_channel, num_layers, batch_size, epochs, cfg=None):
     """How many of `images` may progress together: `wanted`, or fewer where the device's free memory (plus what this
     process's allocator already holds in reserve) does not hold that many of the largest fit at 85 %.  One 8 x 2048^2 tile is
@@ -380,7 +398,8 @@ def fit_group(imgs_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
 
 def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val_duration=1, cfg=None,
              path=ops.PATH_AUTO, seed=19920517, in_flight=None, then=None, draws=None, group=None):
-    """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time (None: 4); returns
+    """Fit several HBM-resident images on ONE GPU with `in_flight` of them progressing at a time (None: default_in_flight of
+    the shape -- 4, or 3 at bc >= 128 --, cut to what the free memory holds); returns
     [then(fit) or fit, ...] in input order.
 
     Why: one fit is a strict chain of short dependent kernels (train step ~16 us on half the chip -> reduce/Adam
@@ -401,7 +420,7 @@ def fit_many(images, K, D, base_channel, num_layers, lr, batch_size, epochs, val
     coding, ...).  `draws`: one FitDraws per image instead of `seed` (the tiles of one image, whose draws the
     caller made in tile order).  Returns after all streams have been joined to the caller's current stream."""
     if in_flight is None:
-        in_flight = 4
+        in_flight = default_in_flight(*tuple(images[0].shape), K, D, base_channel, num_layers, cfg, path) if images else 4
     in_flight = memory_limited_in_flight(images, in_flight, K, D, base_channel, num_layers, batch_size, epochs, cfg)
     if group is None:
         group = int(os.environ.get("LBDRN_FIT_GROUP", "0"))

@@ -438,3 +438,7 @@ def test_fits_in_flight_are_sized_against_the_free_memory(monkeypatch):
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (20 << 30, 288 << 30))
     with pytest.raises(ops._lib.LbdrnError, match="split the image"):
         codec.memory_limited_in_flight([T(8, 6000, 6000)], 4, *args)
+    # what fit_many takes when the caller names no count: two chains of pair launches at bc = 64, three chains of the
+    # three-launch step at bc >= 128 (a fourth only queues: DESIGN 4.5)
+    assert codec.default_in_flight(8, 2048, 2048, 5, 2, 64, 2) == 4
+    assert codec.default_in_flight(8, 2048, 2048, 5, 2, 256, 2) == codec.default_in_flight(8, 2048, 2048, 5, 2, 128, 1) == 3
