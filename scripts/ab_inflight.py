@@ -1,5 +1,5 @@
 """A/B aid: wall time per tile of codec.fit_many over 6 tiles with 1 and 2 fits in flight, for the train
-kernel named by LBDRN_TRAIN_KERNEL (unset = k_train_stream, 'tile' = k_train_mfma)."""
+library named by LBDRN_HIP_LIB (e.g. a variant built with csrc/build.py --variant tile -DLBDRN_EXP_TILE_KERNEL: every shape on k_train_mfma)."""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # like bench.py: one hardware queue per fit in flight
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,4 +17,4 @@ for infl in [int(x) for x in os.environ.get('AB_INFLIGHT', '1,2').split(',')]:
     fits = codec.fit_many(tiles, *args, seed=19920517, in_flight=infl)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / len(tiles)
     out.append(f"in_flight={infl}: {dt*1e3:.2f} ms/tile")
-print(os.environ.get("LBDRN_TRAIN_KERNEL", "mfma"), " | ".join(out), "mse", [round(float(f.mse_log[:, 0].min()), 6) for f in fits[:3]])
+print(os.path.basename(os.environ.get("LBDRN_HIP_LIB", "liblbdrn_hip.so")), " | ".join(out), "mse", [round(float(f.mse_log[:, 0].min()), 6) for f in fits[:3]])

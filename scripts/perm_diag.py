@@ -1,4 +1,6 @@
-"""Diagnostic: ms per tile (16 tiles, four in flight, fits without decode) -- run under LBDRN_RANDPERM_DIAG = 0 / 1 / 2 / 3."""
+"""Diagnostic: ms per tile (16 tiles, four in flight, fits without decode) -- run once per timing-only library variant:
+    python lbdrn-msic_amd/csrc/build.py --variant permdiagN -DLBDRN_EXP_RANDPERM_DIAG=N    (N = 1: no MT19937 launch, 2: none of the
+    launches behind it, 3: neither; the permutations are then garbage) and LBDRN_HIP_LIB=lbdrn-msic_amd/liblbdrn_hip_permdiagN.so"""
 import os, sys, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,4 +16,4 @@ def run():
     torch.cuda.synchronize()
     return (time.perf_counter() - t) / len(tiles) * 1e3
 run()
-print("LBDRN_RANDPERM_DIAG =", os.environ.get("LBDRN_RANDPERM_DIAG", "0"), ["%.2f" % run() for _ in range(3)], "ms per tile")
+print("library =", os.path.basename(os.environ.get("LBDRN_HIP_LIB", "liblbdrn_hip.so")), ["%.2f" % run() for _ in range(3)], "ms per tile")
