@@ -196,12 +196,31 @@ def memory_limited_in_flight(images, wanted, K, D, base_channel, num_layers, bat
     return max(1, min(wanted, fits))
 
 
-def background_steps(steps_per_epoch):
+# What the two launches that share the chip during a lone fit's background evaluation pass achieve, as fractions of the
+# f32-MFMA peak (157.3 TFLOP/s) -- measured, DESIGN.md section 4: the evaluation pass on the whole chip (it runs on half of
+# it in the background: twice as long), and k_train_stream's single-fit launch on its 128 CUs, plus the step's two kernel
+# boundaries and its reduce / Adam launch.
+EVAL_PASS_FRAC_OF_PEAK, HALF_CHIP_STEP_FRAC_OF_PEAK, HALF_CHIP_STEP_OVERHEAD_S, PEAK_FLOPS = 0.65, 0.26, 5.0e-6, 157.3e12
+
+
+def background_steps(steps_per_epoch, net=None, n_pixels=None, batch_size=None):
     """How many steps of an epoch a lone fit takes on the half-chip launch, beside the previous epoch's background
-    evaluation pass (fit_device).  The pass reads the image once on half as many workgroups: 2.8 ms at the headline shape =
-    0.27 of an epoch's 512 steps of 20 us; LBDRN_LONE_HEAD_FRAC overrides the fraction (A/B)."""
-    frac = float(os.environ.get("LBDRN_LONE_HEAD_FRAC", "0.27"))
-    return int(round(frac * steps_per_epoch))
+    evaluation pass (fit_device): as long as that pass takes.  Both durations follow from the shape's FLOP counts and the
+    achieved fractions above -- the pass 2 x N x forward / (0.65 peak), a step B x (forward + backward) / (0.26 peak) + 5 us:
+    2.9 ms against 20.4 us at the headline shape = 0.27 of an epoch's 512 steps, what the sweep over the fraction also found
+    (0.15 / 0.2 / 0.27 / 0.35 / 0.45: 106.4 / 105.5 / 104.3 / 105.7 / 106.5 ms per tile).  The ratio does not depend on the image
+    size.  LBDRN_LONE_HEAD_FRAC overrides it (A/B)."""
+    env = os.environ.get("LBDRN_LONE_HEAD_FRAC")
+    if env is not None:
+        return int(round(float(env) * steps_per_epoch))
+    if net is None:
+        return int(round(0.27 * steps_per_epoch))
+    F, bc, C, nl = int(net.F), int(net.bc), int(net.C), int(net.nl)
+    fwd = 2 * (F * bc + (nl - 1) * bc * bc + bc * C)
+    step = 2 * fwd + 2 * ((nl - 1) * bc * bc + bc * C)       # forward + weight gradients + input gradients of the hidden layers
+    t_pass = 2.0 * n_pixels * fwd / (EVAL_PASS_FRAC_OF_PEAK * PEAK_FLOPS)
+    t_step = min(batch_size, n_pixels) * step / (HALF_CHIP_STEP_FRAC_OF_PEAK * PEAK_FLOPS) + HALF_CHIP_STEP_OVERHEAD_S
+    return max(0, min(steps_per_epoch, int(round(t_pass / t_step))))
 
 
 def _eval_stream(dev, main):
@@ -281,7 +300,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
             # it go out WITHOUT the alone hint -- the half-chip launch that fits on the other half (k_train_stream) --, the
             # rest of the epoch with it (k_train_split, every CU).  Same numbers either way (lbdrn_hip.h: the hint
             # changes no bit), so where the line is drawn is a matter of time only.
-            head = min(steps_per_epoch, background_steps(steps_per_epoch)) if (side is not None and alone and e - 1 in eval_epochs) else 0
+            head = background_steps(steps_per_epoch, net, N, batch_size) if (side is not None and alone and e - 1 in eval_epochs) else 0
             for lo, hi, hint in ((0, head, False), (head, steps_per_epoch, alone)):
                 if hi > lo:
                     ops.train_epoch(geom, net, img_d, msb_d, perm[lo * batch_size:hi * batch_size], batch_size, params, exp_avg,
