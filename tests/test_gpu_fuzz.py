@@ -176,9 +176,9 @@ def test_two_training_kernels_one_set_of_bits_fuzz(dev):
     MFMA = ops._lib.PATH_MFMA
     shapes = [FeatCfg(False, False, 1.4, 12, True, True), FeatCfg(True, True, 1.4, 12, True, True)]
     tails = 0
-    for it in range(10 * SOAK):
+    for it in range(12 * SOAK):
         cfg = shapes[it % 2]
-        C, D, bc, nl = 8, 2, 64, 2
+        C, D, bc, nl = (8, 2, 64, 2) if it % 4 < 2 else (4, 3, 64, 2)   # (4 bands x 7 x 7: the same 192 / 242 features, half the channels)
         H, W, K = int(rng.integers(5, 40)), int(rng.integers(5, 60)), int(rng.integers(1, 8))
         bs = int(rng.choice([33, 64, 65, 100, 257, 1000, H * W - 1, H * W + 7]))
         bs = max(bs, 2)
@@ -192,6 +192,7 @@ def test_two_training_kernels_one_set_of_bits_fuzz(dev):
         F = cfg.feature_dim(C, D)
         geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
         net = ops.make_net(F, bc, C, nl)
+        assert ops.train_step_features(geom, net) in (192, 242)      # (the two shapes that have both kernels)
         p0 = _params(rng, F, bc, C, nl, 1.0)
         perm = torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev)
         img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
