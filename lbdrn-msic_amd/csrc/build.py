@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRCS = ["cabi.hip", "generic.hip", "apply_mfma.hip", "train_mfma.hip", "randperm.hip", "plane_codec.hip", "weights_codec.hip"]
-HDRS = ["common.hpp", "lbdrn_math.hpp", "mt_jump.inc", "train_wide.inc", "train_stream.inc", "apply_wide.inc", "exports.map", "../../include/lbdrn_hip.h"]
+HDRS = sorted(f for f in os.listdir(HERE) if f.endswith((".hpp", ".inc"))) + ["exports.map", "../../include/lbdrn_hip.h"]
 OUT = os.path.join(os.path.dirname(HERE), "liblbdrn_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
