@@ -67,7 +67,12 @@ typedef struct lbdrn_geom {
  * for l in 0..nl-1: W_l[bc][in_l], b_l[bc];  then W_last[C][bc], b_last[C]. */
 typedef struct lbdrn_net {
     int32_t F, bc, C, nl;
+    int32_t act;          /* hidden activation (LBDRNmodel.py:37,75): LBDRN_ACT_SINE = the default Sine(w0 = 30);
+                           * LBDRN_ACT_RELU = LBDRNModel(activation=torch.nn.ReLU()), the alternative the reference names
+                           * (encode.py:75, decode.py:108) -- LDS-tiled generic kernels only: LBDRN_PATH_MFMA answers
+                           * LBDRN_E_UNSUPPORTED, LBDRN_PATH_AUTO takes the generic path.  The head is always Sigmoid. */
 } lbdrn_net;
+enum { LBDRN_ACT_SINE = 0, LBDRN_ACT_RELU = 1 };
 
 const char *lbdrn_last_error(void);
 int lbdrn_abi_version(void);

@@ -7,3 +7,7 @@ SIGMA = 1.4
 N_FREQ = 12
 USE_COLORS = True         # (2D+1)^2 neighbourhood of normalised high bits per band
 RELATIVE = True           # subtract the centre pixel from its neighbourhood
+# Not in the reference's constants.py: the reference switches its hidden activation by editing a source line
+# (`activation=torch.nn.ReLU() # Default: Sine`, commented out at ref encode.py:75 and decode.py:108); this name stands for
+# that edit.  "sine" = Sine(w0 = 30), the fused MFMA kernels; "relu" = torch.nn.ReLU(), the generic LDS-tiled kernels.
+HIDDEN_ACTIVATION = "sine"

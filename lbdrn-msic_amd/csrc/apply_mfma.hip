@@ -63,6 +63,7 @@ struct ApplyPlan {
 
 static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, bool fast = false)
 {
+    if (net.act != LBDRN_ACT_SINE) return false;   // (the fused kernels are the Sine network's: LBDRNmodel.py:37)
     if (net.bc % 32 != 0 || net.bc < 32 || net.bc > 128) return false;
     if (net.C > 32 || net.nl < 1 || net.nl > 15) return false;
     ApplyPlan q;

@@ -46,6 +46,7 @@ int check_net(const lbdrn_net* n)
     LBDRN_REQUIRE(n != nullptr, "net is null");
     LBDRN_REQUIRE(n->F >= 1 && n->bc >= 1 && n->C >= 1 && n->nl >= 1,
                   "bad net F=%d bc=%d C=%d nl=%d", n->F, n->bc, n->C, n->nl);
+    LBDRN_REQUIRE(n->act == LBDRN_ACT_SINE || n->act == LBDRN_ACT_RELU, "unknown hidden activation %d", n->act);
     return 0;
 }
 
@@ -261,7 +262,7 @@ static int launch_gemm(const Prob& p, hipStream_t s)
     return 0;
 }
 
-enum Act { ACT_SIN = 0, ACT_SIGMOID = 1 };
+enum Act { ACT_SIN = 0, ACT_SIGMOID = 1, ACT_RELU = 2 };
 
 // y[b][j] = act(bias[j] + sum_k x[b][k] W[j][k])   (nn.Linear + activation, LBDRNmodel.py:39-43)
 template <int ACT, bool KEEP_COS>
@@ -287,13 +288,30 @@ struct LinearFwd {
             } else {
                 out[(int64_t)m * N + n] = siren_act(z);
             }
+        } else if (ACT == ACT_RELU) {   // nn.ReLU: z where z > 0, else 0; its derivative (1 / 0) in the slot of the cosine
+            out[(int64_t)m * N + n] = z > 0.0f ? z : 0.0f;
+            if (KEEP_COS) cosout[(int64_t)m * N + n] = z > 0.0f ? 1.0f : 0.0f;
         } else {
             out[(int64_t)m * N + n] = canon_sigmoid(z);
         }
     }
 };
 
-// dzprev[b][k] = ((sum_j dz[b][j] W[j][k]) * cos(30 zprev[b][k])) * 30   (autograd of Linear + Sine)
+// one hidden layer of the net's activation
+template <bool KEEP_COS>
+static int launch_hidden(const lbdrn_net& net, int B, int nin, const float* in, const float* W, float* out, float* dact,
+                         hipStream_t s)
+{
+    if (net.act == LBDRN_ACT_RELU) {
+        LinearFwd<ACT_RELU, KEEP_COS> g{B, net.bc, nin, nin, in, W, W + (int64_t)net.bc * nin, out, dact};
+        return launch_gemm(g, s);
+    }
+    LinearFwd<ACT_SIN, KEEP_COS> g{B, net.bc, nin, nin, in, W, W + (int64_t)net.bc * nin, out, dact};
+    return launch_gemm(g, s);
+}
+
+// dzprev[b][k] = ((sum_j dz[b][j] W[j][k]) * cos(30 zprev[b][k])) * 30   (autograd of Linear + Sine); with nn.ReLU the sum
+// where zprev > 0 and zero elsewhere (threshold_backward)
 struct BackDx {
     static constexpr bool a_k_contig = true, b_k_contig = false;
     int M, N, Kd, kchunk;
@@ -301,12 +319,14 @@ struct BackDx {
     const float* W;     // [Kd][N]
     const float* cosv;  // [M][N]
     float* out;         // [M][N]
+    int relu;
     __device__ float a(int m, int k) const { return dz[(int64_t)m * Kd + k]; }
     __device__ float b(int k, int n) const { return W[(int64_t)k * N + n]; }
     __device__ float init(int, int) const { return 0.0f; }
     __device__ void store(int m, int n, float v, int) const
     {
-        out[(int64_t)m * N + n] = (v * cosv[(int64_t)m * N + n]) * 30.0f;
+        const float d = cosv[(int64_t)m * N + n];
+        out[(int64_t)m * N + n] = relu ? (d != 0.0f ? v : 0.0f) : (v * d) * 30.0f;
     }
 };
 
@@ -365,8 +385,7 @@ int generic_forward(const lbdrn_net& net, const float* params, const float* x, i
     int nin = net.F;
     const float* p = params;
     for (int l = 0; l < net.nl; ++l) {
-        LinearFwd<ACT_SIN, false> g{(int)B, net.bc, nin, nin, in, p, p + (int64_t)net.bc * nin, h[l & 1], nullptr};
-        if (int rc = launch_gemm(g, s)) return rc;
+        if (int rc = launch_hidden<false>(net, (int)B, nin, in, p, h[l & 1], nullptr, s)) return rc;
         p += (int64_t)net.bc * nin + net.bc;
         in = h[l & 1];
         nin = net.bc;
@@ -650,8 +669,7 @@ int generic_train_step(const lbdrn_net& net, const float* x, const float* t, int
     int nin = net.F;
     for (int l = 0; l < net.nl; ++l) {
         const float* W = params + layer_offset(net, l);
-        LinearFwd<ACT_SIN, true> g{B, net.bc, nin, nin, in, W, W + (int64_t)net.bc * nin, w.h + l * act, w.cs + l * act};
-        if (int rc = launch_gemm(g, s)) return rc;
+        if (int rc = launch_hidden<true>(net, B, nin, in, W, w.h + l * act, w.cs + l * act, s)) return rc;
         in = w.h + l * act;
         nin = net.bc;
     }
@@ -678,7 +696,7 @@ int generic_train_step(const lbdrn_net& net, const float* x, const float* t, int
     const float* W_up = Wl;
     for (int l = net.nl - 1; l >= 0; --l) {
         float* dz = w.dz[l & 1];
-        BackDx bd{B, net.bc, n_up, n_up, dz_up, W_up, w.cs + l * act, dz};
+        BackDx bd{B, net.bc, n_up, n_up, dz_up, W_up, w.cs + l * act, dz, net.act == LBDRN_ACT_RELU};
         if (int rc = launch_gemm(bd, s)) return rc;
         const int lin = l ? net.bc : net.F;
         const float* lin_act = l ? w.h + (l - 1) * act : x;

@@ -160,7 +160,7 @@ static int stream_lds_total(int LQ, int NL);
 
 static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan* out)
 {
-    if (net.bc != TBC || net.nl < 1 || net.nl > 3 || net.C > 16 || net.F < 1) return false;
+    if (net.act != LBDRN_ACT_SINE || net.bc != TBC || net.nl < 1 || net.nl > 3 || net.C > 16 || net.F < 1) return false;
     TrainPlan p;
     p.RP = (net.F + net.C + 3) / 4 * 4;
     p.LQ = 0;

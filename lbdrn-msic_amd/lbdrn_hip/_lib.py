@@ -33,7 +33,7 @@ class Geom(ctypes.Structure):
 class Net(ctypes.Structure):
     """struct lbdrn_net"""
     _fields_ = [("F", ctypes.c_int32), ("bc", ctypes.c_int32), ("C", ctypes.c_int32),
-                ("nl", ctypes.c_int32)]
+                ("nl", ctypes.c_int32), ("act", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); must list every symbol include/lbdrn_hip.h declares

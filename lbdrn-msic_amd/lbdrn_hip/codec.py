@@ -148,7 +148,7 @@ def fit_bytes(C, H, W, K, D, base_channel, num_layers, batch_size, epochs, cfg=N
     cfg = cfg or FeatCfg.from_constants()
     N = H * W
     g = ops._lib.Geom(C, H, W, K, D, 1, int(cfg.use_colors), int(cfg.relative), int(cfg.P), 0, None, None)
-    net = ops.make_net(cfg.feature_dim(C, D), base_channel, C, num_layers)
+    net = ops.make_net(cfg.feature_dim(C, D), base_channel, C, num_layers, cfg.act)
     L = ops.lib()
     import ctypes
     train = int(L.lbdrn_train_workspace(ctypes.byref(g), ctypes.byref(net), batch_size))
@@ -267,7 +267,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
             # then every pass's sampler seed
             draws = draw_fit(geom.F, base_channel, C, num_layers, epochs, val_duration)
     stream = DevicePermutationStream(N, epochs, val_duration, dev, train_seeds=draws.train_seeds)
-    net = ops.make_net(geom.F, base_channel, C, num_layers)
+    net = ops.make_net(geom.F, base_channel, C, num_layers, cfg.act)
     params = draws.params.to(dev).contiguous()
     if params.numel() != ops.param_count(net):
         raise ValueError("draws were made for another network shape")
@@ -365,7 +365,7 @@ def fit_group(imgs_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
                 if seed is not None:
                     torch.manual_seed(seed)
                 dr = draw_fit(geom.F, base_channel, C, num_layers, epochs, val_duration)
-        net = ops.make_net(geom.F, base_channel, C, num_layers)
+        net = ops.make_net(geom.F, base_channel, C, num_layers, cfg.act)
         params = dr.params.to(dev).contiguous()
         if params.numel() != ops.param_count(net):
             raise ValueError("draws were made for another network shape")
@@ -617,7 +617,7 @@ def apply_image(base, params, K, D, base_channel, num_layers, cfg=None, device="
         msb_max = int(base.max())
     C, H, W = msb_d.shape
     geom = ops.FeatureGeometry(C, H, W, K, D, msb_max, cfg, dev)         # divisor base.max(): decode.py:93
-    net = ops.make_net(geom.F, base_channel, C, num_layers)
+    net = ops.make_net(geom.F, base_channel, C, num_layers, cfg.act)
     p = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float32)).to(dev)
     if p.numel() != ops.param_count(net):
         raise ValueError(f"weight payload has {p.numel()} values, the network needs {ops.param_count(net)}")

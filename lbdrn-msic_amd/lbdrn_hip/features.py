@@ -11,13 +11,17 @@ import numpy as np
 
 class FeatCfg:
     def __init__(self, use_coordinates=False, embedding=False, sigma=1.4, n_freq=12,
-                 use_colors=True, relative=True):
+                 use_colors=True, relative=True, activation="sine"):
         self.use_coordinates = bool(use_coordinates)
         self.embedding = bool(embedding)
         self.sigma = float(sigma)
         self.n_freq = int(n_freq)
         self.use_colors = bool(use_colors)
         self.relative = bool(relative)
+        if activation not in ("sine", "relu"):
+            raise ValueError(f"hidden activation {activation!r}: 'sine' (the reference's default) or 'relu' "
+                             "(ref encode.py:75, decode.py:108)")
+        self.activation = activation
 
     @classmethod
     def from_constants(cls, mod=None):
@@ -25,7 +29,12 @@ class FeatCfg:
         if mod is None:
             import constants as mod
         return cls(mod.USE_COORDINATES, mod.EMBEDDING, mod.SIGMA, mod.N_FREQ, mod.USE_COLORS,
-                   mod.RELATIVE)
+                   mod.RELATIVE, getattr(mod, "HIDDEN_ACTIVATION", "sine"))
+
+    @property
+    def act(self):
+        """lbdrn_net.act (include/lbdrn_hip.h): LBDRN_ACT_SINE = 0, LBDRN_ACT_RELU = 1."""
+        return 1 if self.activation == "relu" else 0
 
     @property
     def P(self):

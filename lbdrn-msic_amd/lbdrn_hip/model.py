@@ -55,21 +55,25 @@ class LBDRNModel(nn.Module):
             for i in range(num_layers)])
         self.last_layer = SirenLayer(dim_hidden, dim_out, w0=w0, use_bias=use_bias,
                                      activation=nn.Sigmoid() if final_activation is None else final_activation)
-        self._fused_ok = (activation is None and final_activation is None and use_bias
-                          and w0 == 30.0 and w0_initial == 30.0 and num_layers >= 1)
+        # What liblbdrn_hip implements: the reference's default (Sine, w0 = 30) and the one alternative it names in its
+        # sources (ref encode.py:75, decode.py:108: `activation=torch.nn.ReLU()`), Sigmoid head, biases on.
+        relu = type(activation) is nn.ReLU
+        self.hip_act = ops.ACT_RELU if relu else ops.ACT_SINE
+        self._fused_ok = ((activation is None and w0 == 30.0 and w0_initial == 30.0 or relu)
+                          and final_activation is None and use_bias and num_layers >= 1)
 
     def flat_parameters(self):
         """state_dict order, one float32 vector (ref encode.py:123-128)."""
         return torch.cat([v.detach().reshape(-1).float() for v in self.state_dict().values()])
 
     def hip_net(self):
-        return ops.make_net(self.dim_in, self.dim_hidden, self.dim_out, self.num_layers)
+        return ops.make_net(self.dim_in, self.dim_hidden, self.dim_out, self.num_layers, self.hip_act)
 
     def forward(self, x):
         if not self._fused_ok:
             raise NotImplementedError(
-                "liblbdrn_hip implements the reference configuration (Sine w0=30 hidden layers, "
-                "Sigmoid head, biases on); custom activations have no HIP kernel")
+                "liblbdrn_hip implements the reference configuration (Sine w0=30 hidden layers, Sigmoid head, biases "
+                "on) and activation=torch.nn.ReLU(); other activations have no HIP kernel")
         if not x.is_cuda:
             raise ops._lib.LbdrnError("LBDRNModel.forward needs a device tensor: this package has no CPU path")
         flat = self.flat_parameters().to(x.device)

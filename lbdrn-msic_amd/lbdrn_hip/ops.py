@@ -63,8 +63,11 @@ class FeatureGeometry:
         return self
 
 
-def make_net(F, bc, C, nl):
-    return Net(F, bc, C, nl)
+ACT_SINE, ACT_RELU = 0, 1     # lbdrn_net.act
+
+
+def make_net(F, bc, C, nl, act=ACT_SINE):
+    return Net(F, bc, C, nl, act)
 
 
 def param_count(net):
@@ -201,7 +204,7 @@ def train_group_max():
 def train_group_size(C, H, W, K, D, cfg, base_channel, num_layers):
     """How many fits of this shape step in one launch per minibatch (lbdrn_train_group_size; 1: grouping gains nothing)."""
     g = Geom(C, H, W, K, D, 1, int(cfg.use_colors), int(cfg.relative), int(cfg.P), 0, None, None)
-    net = Net(cfg.feature_dim(C, D), base_channel, C, num_layers)
+    net = Net(cfg.feature_dim(C, D), base_channel, C, num_layers, cfg.act)
     return int(lib().lbdrn_train_group_size(ctypes.byref(g), ctypes.byref(net)))
 
 

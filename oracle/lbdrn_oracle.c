@@ -201,6 +201,12 @@ static int64_t param_count(int F, int bc, int C, int nl)
 }
 int64_t orc_param_count(int F, int bc, int C, int nl) { return param_count(F, bc, C, nl); }
 
+/* Hidden activation of every SirenLayer of `net` (LBDRNmodel.py:37,75): 0 = Sine(w0 = 30), the default; 1 = torch.nn.ReLU(),
+ * the alternative the reference names at encode.py:75 / decode.py:108.  A process-wide switch (this file is single-threaded
+ * test infrastructure): oracle.py's hidden_activation() context manager sets and restores it. */
+static int g_hidden_relu = 0;
+void orc_set_hidden_activation(int act) { g_hidden_relu = act != 0; }
+
 /* y[j] = b[j] then fmaf over k ascending: nn.Linear, LBDRNmodel.py:32,40 */
 static void linear_row(const float *Wt, const float *b, int nout, int nin, const float *x, float *z)
 {
@@ -225,7 +231,10 @@ static void forward_row(const float *params, int F, int bc, int C, int nl, const
         float *zl = zs ? zs + (int64_t)l * bc : z;
         float *hl = hs ? hs + (int64_t)l * bc : ((l & 1) ? h + bc : h);
         linear_row(p, p + (int64_t)bc * nin, bc, nin, in, zl);
-        for (int j = 0; j < bc; ++j) hl[j] = canon_sincos(30.0f * zl[j], 0); /* Sine: :12-13 */
+        if (g_hidden_relu)
+            for (int j = 0; j < bc; ++j) hl[j] = zl[j] > 0.0f ? zl[j] : 0.0f; /* nn.ReLU */
+        else
+            for (int j = 0; j < bc; ++j) hl[j] = canon_sincos(30.0f * zl[j], 0); /* Sine: :12-13 */
         p += (int64_t)bc * nin + bc;
         in = hl;
         nin = bc;
@@ -359,8 +368,9 @@ int orc_train_step(float *params, float *m, float *v, int F, int bc, int C, int 
             double *gW = g + offW[l], *gb = gW + (int64_t)bc * nin;
             const float *zl = zs + (int64_t)l * bc;
             for (int j = 0; j < bc; ++j) {
-                /* d sin(30 z)/dz = cos(30 z) * 30 */
-                dz[j] = (dh[j] * canon_sincos(30.0f * zl[j], 1)) * 30.0f;
+                /* d sin(30 z)/dz = cos(30 z) * 30; nn.ReLU: threshold_backward, the gradient where z > 0 */
+                dz[j] = g_hidden_relu ? (zl[j] > 0.0f ? dh[j] : 0.0f)
+                                      : (dh[j] * canon_sincos(30.0f * zl[j], 1)) * 30.0f;
                 gb[j] += dz[j];
                 for (int k = 0; k < nin; ++k) gW[(int64_t)j * nin + k] += (double)dz[j] * in[k];
             }

@@ -4,6 +4,7 @@ TEST INFRASTRUCTURE ONLY (see oracle/lbdrn_oracle.c header): imported by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product.
 Citations are relative to /root/reference.
 """
+import contextlib
 import ctypes
 import os
 import sys
@@ -92,6 +93,19 @@ def pos_tables(H, W, cfg):
 
 
 # ---------------------------------------------------------------- a1/a2/a3
+
+
+@contextlib.contextmanager
+def hidden_activation(name):
+    """Run the oracle's network functions with this hidden activation: 'sine' (Sine(w0 = 30), ref LBDRNmodel.py:37) or
+    'relu' (torch.nn.ReLU(), the alternative named at ref encode.py:75 / decode.py:108)."""
+    if name not in ("sine", "relu"):
+        raise ValueError(name)
+    lib().orc_set_hidden_activation(1 if name == "relu" else 0)
+    try:
+        yield
+    finally:
+        lib().orc_set_hidden_activation(0)
 
 
 def split_bits(img, K):

@@ -352,7 +352,11 @@ def test_constants_and_log_record_layout_equal_the_reference(tmp_path):
     import logger as L
     with open(os.path.join(ROOT, "tests", "golden", "misc.json")) as f:
         G = json.load(f)
-    assert {k: getattr(C, k) for k in dir(C) if k.isupper()} == G["constants"]
+    mine = {k: getattr(C, k) for k in dir(C) if k.isupper()}
+    # one name the reference does not have: it stands for the reference's "edit this source line" switch of the hidden
+    # activation (ref encode.py:75, decode.py:108), and its default is the reference's default
+    assert mine.pop("HIDDEN_ACTIVATION") == "sine"
+    assert mine == G["constants"]
     L.create_logger(str(tmp_path / "sub" / "dir"), "run.txt", log_file_only=True)
     L.log.info("MSE: 1.25")
     L.log.info(f"Total size: {1234} bytes, bpsp={0.5}")
@@ -442,3 +446,39 @@ def test_fits_in_flight_are_sized_against_the_free_memory(monkeypatch):
     # three-launch step at bc >= 128 (a fourth only queues: DESIGN 4.5)
     assert codec.default_in_flight(8, 2048, 2048, 5, 2, 64, 2) == 4
     assert codec.default_in_flight(8, 2048, 2048, 5, 2, 256, 2) == codec.default_in_flight(8, 2048, 2048, 5, 2, 128, 1) == 3
+
+
+def test_hidden_activation_switch_host_side():
+    """lbdrn_net.act on the host side: FeatCfg / constants.HIDDEN_ACTIVATION -> the descriptor; the drop-in model maps
+    torch.nn.ReLU() (ref encode.py:75) to it and initialises exactly as the default model does (the activation owns no
+    parameter and draws nothing: ref LBDRNmodel.py:32-37)."""
+    import ctypes
+    import subprocess
+    import tempfile
+    import torch
+    from lbdrn_hip import _lib, ops
+    from lbdrn_hip.features import FeatCfg
+    from lbdrn_hip.model import LBDRNModel
+    assert FeatCfg().act == 0 and FeatCfg(activation="relu").act == 1 and FeatCfg.from_constants().act == 0
+    with pytest.raises(ValueError):
+        FeatCfg(activation="tanh")
+    assert ops.make_net(200, 64, 8, 2).act == ops.ACT_SINE and ops.make_net(200, 64, 8, 2, ops.ACT_RELU).act == 1
+    # the ctypes mirror has the header's size and field offsets (gcc on include/lbdrn_hip.h)
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include <stddef.h>\n#include "lbdrn_hip.h"\nint main(void){printf("%zu %zu %d %d %d",'
+                    'sizeof(lbdrn_net), offsetof(lbdrn_net, act), LBDRN_ACT_SINE, LBDRN_ACT_RELU, LBDRN_ABI_VERSION);return 0;}\n')
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(d, "s")])
+        got = subprocess.check_output([os.path.join(d, "s")]).decode().split()
+    assert [int(x) for x in got] == [ctypes.sizeof(_lib.Net), _lib.Net.act.offset, ops.ACT_SINE, ops.ACT_RELU, _lib.ABI_VERSION]
+    torch.manual_seed(5)
+    a = LBDRNModel(200, 64, 8, 2)
+    ra = torch.rand(1)
+    torch.manual_seed(5)
+    b = LBDRNModel(200, 64, 8, 2, activation=torch.nn.ReLU())
+    rb = torch.rand(1)
+    assert torch.equal(a.flat_parameters(), b.flat_parameters()) and torch.equal(ra, rb)
+    assert a.hip_net().act == ops.ACT_SINE and b.hip_net().act == ops.ACT_RELU
+    assert not LBDRNModel(200, 64, 8, 2, activation=torch.nn.Tanh())._fused_ok
+    assert not LBDRNModel(200, 64, 8, 2, activation=torch.nn.ReLU(), final_activation=torch.nn.Identity())._fused_ok
