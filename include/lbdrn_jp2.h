@@ -38,6 +38,11 @@ int lbdrn_jp2_decode(const uint8_t *buf, size_t bytes, uint16_t *planes, int32_t
 
 void lbdrn_jp2_free(uint8_t *p);
 
+/* Worker threads OpenJPEG may use inside ONE encode / decode call from now on (process-wide; 0 or 1: none, the
+ * library's default; at most 256).  The code blocks of a tile are coded independently, so the stream's bytes and the
+ * decoded values do not depend on it.  Returns the previous setting. */
+int lbdrn_jp2_set_threads(int32_t n);
+
 #if defined(__GNUC__)
 #pragma GCC visibility pop
 #endif

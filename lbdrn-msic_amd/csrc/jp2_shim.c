@@ -18,6 +18,15 @@ static void set_err(const char *fmt, ...)
     va_end(ap);
 }
 const char *lbdrn_jp2_last_error(void) { return g_err; }
+/* worker threads OpenJPEG may use inside one call (code blocks are independent: the bytes do not depend on it) */
+static int g_threads = 0;
+int lbdrn_jp2_set_threads(int32_t n)
+{
+    const int old = g_threads;
+    if (n >= 0 && n <= 256) g_threads = n;
+    return old;
+}
+
 static void on_error(const char *msg, void *u) { (void)u; set_err("openjpeg: %s", msg); }
 static void on_quiet(const char *msg, void *u) { (void)msg; (void)u; }
 
@@ -151,6 +160,7 @@ int lbdrn_jp2_encode(const uint16_t *planes, int32_t C, int32_t H, int32_t W, in
     opj_set_warning_handler(codec, on_quiet, NULL);
     opj_set_info_handler(codec, on_quiet, NULL);
     if (!opj_setup_encoder(codec, &prm, img)) { if (!g_err[0]) set_err("opj_setup_encoder failed"); goto done; }
+    if (g_threads > 1 && opj_has_thread_support()) (void)opj_codec_set_threads(codec, g_threads);   /* (between setup and start) */
     st = open_stream(&mem, 0);
     if (!st) { set_err("opj_stream_create failed"); goto done; }
     g_err[0] = 0;
@@ -195,6 +205,7 @@ static int decode_impl(const uint8_t *buf, size_t bytes, uint16_t *planes, int32
     opj_set_info_handler(codec, on_quiet, NULL);
     g_err[0] = 0;
     if (!opj_setup_decoder(codec, &prm)) { if (!g_err[0]) set_err("opj_setup_decoder failed"); goto done; }
+    if (g_threads > 1 && opj_has_thread_support()) (void)opj_codec_set_threads(codec, g_threads);
     st = open_stream(&mem, 1);
     if (!st) { set_err("opj_stream_create failed"); goto done; }
     if (!opj_read_header(st, codec, &img) || !img) { if (!g_err[0]) set_err("openjpeg: cannot read the header"); goto done; }

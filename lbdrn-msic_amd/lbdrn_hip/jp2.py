@@ -34,8 +34,28 @@ def lib():
         L.lbdrn_jp2_decode.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         L.lbdrn_jp2_free.argtypes = [u8p]
         L.lbdrn_jp2_free.restype = None
+        L.lbdrn_jp2_set_threads.argtypes = [ctypes.c_int32]
+        # OpenJPEG codes the code blocks of a call on this many worker threads (same bytes): LBDRN_JP2_THREADS, default
+        # up to 8 of the host's cores -- a 8 x 2048 x 2048 plane set takes seconds of ONE core otherwise
+        L.lbdrn_jp2_set_threads(default_threads())
         _lib = L
     return _lib
+
+
+def default_threads():
+    v = os.environ.get("LBDRN_JP2_THREADS")
+    if v is not None:
+        return max(0, int(v))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    return min(8, n)
+
+
+def set_threads(n):
+    """Worker threads OpenJPEG may use inside one encode / decode call (lbdrn_jp2_set_threads); returns the previous value."""
+    return int(lib().lbdrn_jp2_set_threads(int(n)))
 
 
 def available():

@@ -24,7 +24,8 @@ def jp2():
 def test_jp2_library_exports_every_declared_symbol(jp2):
     hdr = open(os.path.join(ROOT, "include", "lbdrn_jp2.h")).read()
     declared = set(re.findall(r"\b(lbdrn_jp2_[a-z_0-9]+)\s*\(", hdr))
-    assert declared == {"lbdrn_jp2_last_error", "lbdrn_jp2_encode", "lbdrn_jp2_info", "lbdrn_jp2_decode", "lbdrn_jp2_free"}
+    assert declared == {"lbdrn_jp2_last_error", "lbdrn_jp2_encode", "lbdrn_jp2_info", "lbdrn_jp2_decode", "lbdrn_jp2_free",
+                        "lbdrn_jp2_set_threads"}
     L = ctypes.CDLL(jp2._PATH)
     for name in declared:
         assert hasattr(L, name), name
@@ -50,6 +51,26 @@ def test_lossless_round_trip_of_multiband_planes(jp2):
         assert z.dtype == dt and np.array_equal(x, z)
     flat = np.zeros((2, 64, 64), np.uint16)
     assert len(jp2.encode(flat)) < 1000      # an all-zero plane costs its headers
+
+
+def test_worker_threads_change_no_byte(jp2):
+    """lbdrn_jp2_set_threads: OpenJPEG codes a call's code blocks on worker threads; the stream and the decoded values are
+    those of the single-threaded call (tiled and untiled rasters)."""
+    rng = np.random.default_rng(8)
+    old = jp2.set_threads(1)
+    try:
+        for shape in ((8, 300, 260), (3, 1100, 1030)):
+            x = (rng.integers(0, 300, shape) + np.arange(shape[2])[None, None, :] // 7).astype(np.uint16)
+            one = jp2.encode(x)
+            assert jp2.set_threads(4) == 1
+            four = jp2.encode(x)
+            assert four == one and np.array_equal(jp2.decode(one), x)
+            assert jp2.set_threads(1) == 4
+            assert np.array_equal(jp2.decode(four), x)
+        assert jp2.set_threads(100000) == 1 and jp2.set_threads(1) == 1      # (out of range: refused, setting unchanged)
+    finally:
+        jp2.set_threads(old)
+    assert 0 <= jp2.default_threads() <= 8
 
 
 def test_damaged_and_foreign_streams_are_refused(jp2):
