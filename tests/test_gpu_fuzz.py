@@ -301,10 +301,17 @@ def test_split_labels_features_fuzz_equal_oracle(dev):
         assert np.array_equal(l.view(np.int32), lo.view(np.int32)), tag
 
 
-def test_forward_and_step_fuzz_any_width_equal_oracle(dev):
+@pytest.mark.parametrize("act", ["sine", "relu"])
+def test_forward_and_step_fuzz_any_width_equal_oracle(dev, act):
     """lbdrn_forward / lbdrn_train_step take any F, bc, C, nl, B (the generic MFMA GEMM with ragged tiles
-    and split-K): forward bit-exact, the step within the training tolerance."""
+    and split-K): forward bit-exact, the step within the training tolerance -- under both hidden activations the
+    library knows (lbdrn_net.act: Sine(30), and the reference's named alternative torch.nn.ReLU())."""
     rng = np.random.default_rng(11)
+    with O.hidden_activation(act):
+        _forward_and_step_fuzz(dev, rng, ops.ACT_RELU if act == "relu" else ops.ACT_SINE, 30.0 if act == "relu" else 1.5)
+
+
+def _forward_and_step_fuzz(dev, rng, hip_act, gain):
     for it in range(16 * SOAK):
         F = int(rng.integers(1, 300))
         bc = int(rng.choice([1, 7, 32, 64, 65, 100, 128, 200, 256, 300]))
@@ -312,10 +319,10 @@ def test_forward_and_step_fuzz_any_width_equal_oracle(dev):
         nl = int(rng.integers(1, 5))
         B = int(rng.choice([1, 3, 63, 64, 65, 255, 1000, 4097]))
         tag = (it, F, bc, C, nl, B)
-        pn = _params(rng, F, bc, C, nl, 1.5)
+        pn = _params(rng, F, bc, C, nl, gain)   # (ReLU: weights of the size Sine's w0 = 30 would have made them)
         x = rng.uniform(-1, 1, (B, F)).astype(np.float32)
         t = rng.uniform(0, 1, (B, C)).astype(np.float32)
-        net = ops.make_net(F, bc, C, nl)
+        net = ops.make_net(F, bc, C, nl, hip_act)
         p = torch.from_numpy(pn).to(dev)
         xd, td = torch.from_numpy(x).to(dev), torch.from_numpy(t).to(dev)
         y = ops.forward(net, p, xd).cpu().numpy()

@@ -156,7 +156,7 @@ def test_a_whole_fit_and_the_clis_with_relu(dev, tmp_path, monkeypatch):
     src = str(tmp_path / "t.npy")
     raster_io.write_raster(src, img)
     out = str(tmp_path / "o")
-    assert encode.main(["-i", src, "-o", out, "-e", "2", "-bs", "512", "-bc", "32"]) in (0, None)
+    assert encode.main(["-i", src, "-o", out, "-e", "2", "-bs", "256", "-bc", "32", "-sr", "2"]) in (0, None)   # (four tiles: fit_many)
     sub = [d for d in (tmp_path / "o").iterdir() if d.is_dir()][0]
     assert decode.main(["-i", str(sub / "t.bin")]) in (0, None)      # (without -org: the raster stays for the checks)
     rec = raster_io.read_raster(str(sub / "t_recon.tif"))
