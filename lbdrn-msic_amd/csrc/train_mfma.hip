@@ -1408,7 +1408,11 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
 #ifdef LBDRN_EXP_NO_SPLIT   // (A/B build: the lone fit stays on k_train_stream)
     const bool split = false;
 #else
+#ifdef LBDRN_EXP_SPLIT_ALIAS_LDS   // (timing only: every launch on k_train_split, groups included -- two workgroups per CU)
+    const bool split = split_available(A.p, net);
+#else
     const bool split = alone && count == 1 && split_available(A.p, net);
+#endif
 #endif
     const int red_blocks = A.p.slab_floats / (4 * RED_LANES);
     int64_t step = step0;
