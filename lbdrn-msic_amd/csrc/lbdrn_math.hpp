@@ -103,7 +103,7 @@ LBDRN_DEV float canon_exp_neg(float a)
     r = fma_(-n, kLn2B, r);
     float e = fma_(fma_(fma_(fma_(kExp4, r, kExp3), r, kExp2), r, kExp1), r, kExp0);
     float p = fma_(r * r, e, r) + 1.0f;
-    int bits = __float_as_int(p) + (((int)n) << 23);
+    int bits = __float_as_int(p) + (int)n * (1 << 23);   // (n <= 0: a multiplication, not a shift of a negative value)
     return __int_as_float(bits);
 }
 

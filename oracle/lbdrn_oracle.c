@@ -72,7 +72,7 @@ static inline float canon_exp_neg(float a)
     float p = fmaf(r * r, e, r) + 1.0f;
     int32_t bits;
     memcpy(&bits, &p, 4);
-    bits += ((int32_t)n) << 23;
+    bits += (int32_t)n * (1 << 23);   /* (n <= 0: a multiplication, not a shift of a negative value) */
     memcpy(&p, &bits, 4);
     return p;
 }
