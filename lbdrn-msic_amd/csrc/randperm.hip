@@ -338,7 +338,10 @@ __global__ void __launch_bounds__(256)
 // pair index, so that a walk is one 8-byte load per entry), then for every position the predecessors of its list's steps
 // (pred[step]) and the latest step below it (last[position]).  Lists up to LINK_REG entries are ordered in registers,
 // longer ones (the far end of the array: ~ln n entries) in a per-thread strip of LDS.
-constexpr int LINK_LDS = 24;   // entries of a thread's LDS strip; longer lists (a handful per permutation) re-walk
+#ifndef LBDRN_LINK_LDS
+#define LBDRN_LINK_LDS 24
+#endif
+constexpr int LINK_LDS = LBDRN_LINK_LDS;   // entries of a thread's LDS strip; longer lists (a handful per permutation) re-walk
 constexpr int LINK_THREADS = 512;   // the walks are chains of dependent loads: sixteen waves per CU keep more of them in flight
                                     // (256 threads: 204 us per launch, 512: 141; 1024 with strips of 12 entries: 206)
 __global__ void __launch_bounds__(LINK_THREADS)
