@@ -37,7 +37,8 @@ extern "C" {
 
 /* 2 (round 5): the `path` word of lbdrn_train_epoch gained LBDRN_TRAIN_ALONE and of lbdrn_eval_sse LBDRN_EVAL_FAST /
  * LBDRN_EVAL_BACKGROUND, lbdrn_train_group_size / lbdrn_train_step_features were added, and the fused step's
- * weight-gradient summation tree changed (still one fixed tree: see lbdrn_train_epoch). */
+ * weight-gradient summation tree changed (still one fixed tree: see lbdrn_train_epoch); struct lbdrn_net gained `act`
+ * (20 bytes instead of 16: a caller built against version 1 passes a shorter struct and must be rebuilt). */
 #define LBDRN_ABI_VERSION 2
 
 typedef enum lbdrn_status {
