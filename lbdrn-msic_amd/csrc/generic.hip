@@ -355,8 +355,19 @@ __global__ void __launch_bounds__(256)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= M * N) return;
+    // (sixteen loads in flight, added in z order: one load per add made the launch a chain of memory latencies -- 9.4 us for the
+    //  32 slices of an 8192-row minibatch, a fifth of the generic step)
     float acc = 0.0f;
-    for (int z = 0; z < slices; ++z) acc += part[(int64_t)z * M * N + e];
+    const int64_t MN = (int64_t)M * N;
+    int z = 0;
+    for (; z + 16 <= slices; z += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = part[(int64_t)(z + u) * MN + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += t[u];
+    }
+    for (; z < slices; ++z) acc += part[(int64_t)z * MN + e];
     int m = e / N, n = e - m * N;
     if (n < N - 1) gW[(int64_t)m * (N - 1) + n] = acc;
     else gb[m] = acc;
