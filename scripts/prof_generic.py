@@ -1,5 +1,8 @@
+"""One epoch of a ReLU fit of the headline tile -- the generic (LDS-tiled GEMM) kernels -- for a rocprofv3 kernel trace:
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_generic -o gp -- python3 scripts/prof_generic.py
+    python scripts/rocprof_kernel_stats.py gpurun_out/prof_generic/gp_results.db profiles/rNN_kernel_stats_generic_relu.csv"""
 import os, sys, time
-sys.path.insert(0, "lbdrn-msic_amd")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lbdrn-msic_amd"))
 import torch
 from lbdrn_hip import codec, ops
 from lbdrn_hip.features import FeatCfg
