@@ -6,7 +6,7 @@
 
 namespace lbdrn {
 const char* last_error();
-bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net);
+bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net, int bs = 0);
 int mfma_train_step_features(const lbdrn_geom& g, const lbdrn_net& net);
 bool mfma_train_takes_groups(const lbdrn_geom& g, const lbdrn_net& net);
 size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
@@ -195,7 +195,7 @@ size_t lbdrn_train_workspace(const lbdrn_geom* g, const lbdrn_net* net, int32_t 
 {
     if (check_geom(g) || check_net(net) || batch_size < 1) return 0;
     size_t a = generic_train_workspace(*net, batch_size);
-    size_t b = mfma_train_supported(*g, *net) ? mfma_train_workspace(*g, *net, batch_size) : 0;
+    size_t b = mfma_train_supported(*g, *net, batch_size) ? mfma_train_workspace(*g, *net, batch_size) : 0;
     return a > b ? a : b;
 }
 
@@ -209,9 +209,9 @@ int lbdrn_train_prepare(const lbdrn_geom* g, const lbdrn_net* net, const uint16_
     LBDRN_REQUIRE(img && msb && batch_size >= 1, "null pointer or bad batch size");
     LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
     NEED_DEVICE();
-    const bool ok = mfma_train_supported(*g, *net);
+    const bool ok = mfma_train_supported(*g, *net, batch_size);
     if (path == LBDRN_PATH_MFMA && !ok) {
-        set_error("fused MFMA train kernel does not support this shape");
+        set_error("fused MFMA train kernel does not support this shape or minibatch size");
         return LBDRN_E_UNSUPPORTED;
     }
     if (ok && path != LBDRN_PATH_GENERIC)
@@ -233,9 +233,9 @@ int lbdrn_train_epoch(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t*
     NEED_DEVICE();
     const bool alone = (path & LBDRN_TRAIN_ALONE) != 0;   // a hint (lbdrn_hip.h): performance only
     path &= ~LBDRN_TRAIN_ALONE;
-    const bool ok = mfma_train_supported(*g, *net);
+    const bool ok = mfma_train_supported(*g, *net, batch_size);
     if (path == LBDRN_PATH_MFMA && !ok) {
-        set_error("fused MFMA train kernel does not support this shape");
+        set_error("fused MFMA train kernel does not support this shape or minibatch size");
         return LBDRN_E_UNSUPPORTED;
     }
     LBDRN_REQUIRE(path >= LBDRN_PATH_AUTO && path <= LBDRN_PATH_MFMA, "unknown path %d", path);
@@ -284,7 +284,7 @@ int lbdrn_train_epoch_group(int32_t count, const lbdrn_geom* const* g, const lbd
     NEED_DEVICE();
     // side by side on the fused step where the shape has one; otherwise (and for any shape the group launch does not
     // take) one after another: same numbers either way
-    if (count > 1 && path != LBDRN_PATH_GENERIC && mfma_train_supported(*g[0], *net)) {
+    if (count > 1 && path != LBDRN_PATH_GENERIC && mfma_train_supported(*g[0], *net, batch_size)) {
         const int rc = mfma_train_epoch_group(count, *g[0], *net, perm, n, batch_size, params, exp_avg, exp_avg_sq,
                                               adam_step0, lr, losses, workspace, workspace_bytes, (hipStream_t)stream, false);
         if (rc != LBDRN_E_UNSUPPORTED) return rc;

@@ -168,7 +168,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
     int kind = net.nl <= 2 ? train_kernel_choice() : 0;
     if (kind == 2) {   // the streamed step: features in 4 LQ slots, labels in a group of their own
         p.fm = centre_skipping_map(g, net);
-        for (int lq : {16, 32, 48, 52, 64})
+        for (int lq : {16, 24, 32, 48, 52, 64})   // (24: the reference's 4-band shape -- F = 100, 96 features that can differ from zero)
             if (p.fm.Fe <= 4 * lq) { p.LQ = lq; break; }
         if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 0; p.LQ = 0; p.fm = FeatMap{net.F, 0, 0, 0}; }
     }
@@ -229,10 +229,14 @@ static bool make_wide_plan(const lbdrn_geom& g, const lbdrn_net& net, WidePlan* 
 static bool wide_supported(const lbdrn_geom& g, const lbdrn_net& net);
 static size_t wide_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs);
 
-bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net)
+static bool slabs_addressable(const TrainPlan& p, int bs);
+
+// bs > 0: ... at that minibatch size (k_reduce_adam addresses one step's slabs through a buffer resource: 32-bit offsets)
+bool mfma_train_supported(const lbdrn_geom& g, const lbdrn_net& net, int bs)
 {
     TrainPlan p;
-    return make_train_plan(g, net, &p) || wide_supported(g, net);
+    if (make_train_plan(g, net, &p)) return bs <= 0 || slabs_addressable(p, bs);
+    return wide_supported(g, net);
 }
 
 bool mfma_train_takes_groups(const lbdrn_geom& g, const lbdrn_net& net)
@@ -264,6 +268,15 @@ static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, 
     L.off_map = o; o += align_up((size_t)p.slab_floats * 4 * sizeof(int), 256);  // slab element -> (param, fragment slots)
     L.total = o;
     return L;
+}
+
+// One step's set of slabs is read through ONE buffer resource with 32-bit byte offsets (k_reduce_adam): it must stay below
+// 2 GiB -- ~1 M rows per minibatch at the headline shape (a slab is 73 KB per 32 rows).  Larger minibatches take the
+// generic step (LBDRN_PATH_AUTO) or are refused (LBDRN_PATH_MFMA): ADVICE round 5.
+static bool slabs_addressable(const TrainPlan& p, int bs)
+{
+    const size_t nwg = std::max((size_t)(bs + TB - 1) / TB, 2 * ((size_t)(bs + WB - 1) / WB));
+    return nwg * (size_t)p.slab_floats * sizeof(float) < ((size_t)1 << 31);
 }
 
 size_t mfma_train_workspace(const lbdrn_geom& g, const lbdrn_net& net, int bs)
@@ -1233,8 +1246,9 @@ static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
     const bool one = A.net.nl == 1;
-    // the two shapes BASELINE.json names (F = 200: 13 strips, F = 250: 16) run the straight-line weight-gradient
-    // schedule (-DLBDRN_EXP_STREAM_LOOP: A/B build that keeps them on the loop)
+    // the shapes BASELINE.json names (F = 200: 12 strips of features that can differ from zero, F = 250: 16) and the
+    // reference's 4-band shape (F = 100: 6) run the straight-line weight-gradient schedule (-DLBDRN_EXP_STREAM_LOOP: A/B
+    // build that keeps them on the loop)
 #ifdef LBDRN_EXP_STREAM_LOOP
     constexpr bool loop_only = true;
 #else
@@ -1242,6 +1256,9 @@ static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s
 #endif
     switch (A.p.LQ) {
         case 16: return one ? launch_stream<16, 1, 0>(A, nwg, count, s) : launch_stream<16, 2, 0>(A, nwg, count, s);
+        case 24:
+            if (!one && A.p.NT0 == 6 && !loop_only) return launch_stream<24, 2, 6>(A, nwg, count, s);
+            return one ? launch_stream<24, 1, 0>(A, nwg, count, s) : launch_stream<24, 2, 0>(A, nwg, count, s);
         case 32: return one ? launch_stream<32, 1, 0>(A, nwg, count, s) : launch_stream<32, 2, 0>(A, nwg, count, s);
         case 48:
             if (!one && A.p.NT0 == 12 && !loop_only) return launch_stream<48, 2, 12>(A, nwg, count, s);
@@ -1255,10 +1272,11 @@ static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s
     }
 }
 
-// the shapes that have k_train_split beside k_train_stream (same bits: train_split.inc) -- the two BASELINE.json names
+// the shapes that have k_train_split beside k_train_stream (same bits: train_split.inc) -- the two BASELINE.json names and
+// the 4-band shape of the reference's own image list (run.sh:14-28)
 static bool split_available(const TrainPlan& p, const lbdrn_net& net)
 {
-    return p.wave == 2 && net.nl == 2 && ((p.LQ == 48 && p.NT0 == 12) || (p.LQ == 64 && p.NT0 == 16));
+    return p.wave == 2 && net.nl == 2 && ((p.LQ == 48 && p.NT0 == 12) || (p.LQ == 64 && p.NT0 == 16) || (p.LQ == 24 && p.NT0 == 6));
 }
 
 template <int LQ, int NT0C>
@@ -1275,7 +1293,7 @@ static int launch_split(const TrainArgs& A, int nwg, int count, hipStream_t s)
 
 static int dispatch_split(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
-    return A.p.LQ == 48 ? launch_split<48, 12>(A, nwg, count, s) : launch_split<64, 16>(A, nwg, count, s);
+    return A.p.LQ == 48 ? launch_split<48, 12>(A, nwg, count, s) : A.p.LQ == 24 ? launch_split<24, 6>(A, nwg, count, s) : launch_split<64, 16>(A, nwg, count, s);
 }
 
 static int dispatch_train(const TrainArgs& A, int nwg, int count, hipStream_t s)
@@ -1353,6 +1371,10 @@ int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net,
     }
     if (count < 1 || count > MAX_GROUP || (count > 1 && A.p.wave != 2)) {
         set_error("a group of %d fits is not supported by this shape's train kernel", count);
+        return LBDRN_E_UNSUPPORTED;
+    }
+    if (!slabs_addressable(A.p, bs)) {
+        set_error("minibatch of %d rows: one step's gradient slabs pass 2 GiB, the fused step does not address them", bs);
         return LBDRN_E_UNSUPPORTED;
     }
     const TrainWsLayout L = train_ws_layout(g, net, A.p, bs);

@@ -33,7 +33,9 @@ CASES = [
     # C, H, W, K, D, nl, bs, flags(coords, embed, colors, relative)
     (8, 40, 52, 5, 2, 2, 512, (0, 0, 1, 1)),      # F=200: the north-star shape (192 features multiplied, LQ=48), short last batch
     (8, 40, 52, 5, 2, 2, 512, (0, 0, 1, 0)),      # F=200 with absolute colours: no feature is an exact zero, LQ=52
-    (4, 30, 41, 5, 2, 1, 300, (0, 0, 1, 1)),      # F=100 (LQ=32), one hidden layer, ragged workgroups
+    (4, 30, 41, 5, 2, 1, 300, (0, 0, 1, 1)),      # F=100 (LQ=24), one hidden layer, ragged workgroups
+    (4, 30, 41, 5, 2, 2, 300, (0, 0, 1, 1)),      # F=100, two hidden layers: the reference's 4-band shape (96 features multiplied, six strips)
+    (5, 30, 41, 5, 2, 2, 300, (0, 0, 1, 1)),      # F=125: 120 features multiplied (LQ=32, eight strips) -- the loop schedule at two hidden layers
     (3, 25, 33, 3, 1, 3, 256, (0, 0, 1, 1)),      # F=27 (LQ=16), three hidden layers
     (16, 20, 24, 6, 0, 2, 128, (0, 0, 1, 1)),     # D=0: F=C=16, all 16 output slots used
     (8, 24, 36, 5, 2, 2, 400, (1, 1, 1, 1)),      # F=250 (LQ=64): positional embedding, config 5
@@ -44,8 +46,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("alone", (False, True))
 @pytest.mark.parametrize("case", CASES)
-def test_mfma_epoch_matches_generic_and_oracle(dev, case):
+def test_mfma_epoch_matches_generic_and_oracle(dev, case, alone):
+    """(alone: the LBDRN_TRAIN_ALONE hint on the fused path -- k_train_split where the shape has it, held to the oracle
+    directly; the shapes with one kernel ignore it.)"""
     C, H, W, K, D, nl, bs, flags = case[:8]
     bc = case[8] if len(case) > 8 else 64
     rng = np.random.default_rng(sum(case[:7]))
@@ -66,7 +71,7 @@ def test_mfma_epoch_matches_generic_and_oracle(dev, case):
         p = torch.from_numpy(p0.copy()).to(dev)
         m, v = torch.zeros_like(p), torch.zeros_like(p)
         losses = torch.zeros(nsteps, dtype=torch.float32, device=dev)
-        ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 3, 1e-3, losses, path=path)
+        ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 3, 1e-3, losses, path=path, alone=alone and path == MFMA)
         res[path] = (p.cpu().numpy(), m.cpu().numpy(), v.cpu().numpy(), losses.cpu().numpy())
     # oracle, step by step
     feats = O.features(msb, D, ocfg, mx)
@@ -143,7 +148,9 @@ def test_alone_hint_changes_no_number(dev):
     plain, embed = FeatCfg(False, False, 1.4, 12, True, True), FeatCfg(True, True, 1.4, 12, True, True)
     for (C, H, W, K, D, nl, bc, bs, cfg) in [(8, 70, 90, 5, 2, 2, 64, 512, plain), (3, 33, 47, 4, 1, 1, 64, 256, plain),
                                              (8, 40, 52, 5, 2, 2, 256, 512, plain), (8, 24, 20, 5, 2, 2, 64, 96, embed),
-                                             (8, 30, 31, 5, 2, 2, 64, 77, plain), (8, 9, 11, 5, 2, 2, 64, 8192, plain)]:
+                                             (8, 30, 31, 5, 2, 2, 64, 77, plain), (8, 9, 11, 5, 2, 2, 64, 8192, plain),
+                                             (4, 70, 90, 5, 2, 2, 64, 512, plain), (4, 30, 31, 5, 2, 2, 64, 77, plain),   # the 4-band shape: k_train_split<24, 6>
+                                             (4, 13, 5, 5, 2, 2, 64, 64, plain)]:                                         # ... 65 rows: a tail minibatch of ONE row
         img = synthetic_tile(5, C, H, W)
         msb, lab, mx = O.split_bits(img, K)
         F = cfg.feature_dim(C, D)
