@@ -63,7 +63,9 @@ struct ApplyPlan {
 
 static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, bool fast = false)
 {
-    if (net.act != LBDRN_ACT_SINE) return false;   // (the fused kernels are the Sine network's: LBDRNmodel.py:37)
+    // hidden activation: Sine(30) (LBDRNmodel.py:37) or nn.ReLU (the alternative of encode.py:75 / decode.py:108): a template
+    // parameter of k_apply_mfma
+    if (net.act != LBDRN_ACT_SINE && net.act != LBDRN_ACT_RELU) return false;
     if (net.bc % 32 != 0 || net.bc < 32 || net.bc > 128) return false;
     if (net.C > 32 || net.nl < 1 || net.nl > 15) return false;
     ApplyPlan q;
@@ -258,7 +260,15 @@ __device__ __forceinline__ void layer0_pair(f32x16 (&acc)[NT], const float* wc, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NT, int MODE>
+// hidden activation of one accumulator entry.  RELU: z where z > 0, else 0 (torch.nn.ReLU: the same in every arithmetic)
+template <int MODE, bool RELU>
+__device__ __forceinline__ float apply_hidden_act(float z)
+{
+    if constexpr (RELU) return z > 0.0f ? z : 0.0f;
+    else return MODE == MODE_EVAL_FAST ? fast_sin(30.0f * z) : siren_act(z);
+}
+
+template <int NT, int MODE, bool RELU>
 __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -481,7 +491,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hid[tt][r] = MODE == MODE_EVAL_FAST ? fast_sin(30.0f * acc[tt][r]) : siren_act(acc[tt][r]);
+                for (int r = 0; r < 16; ++r) hid[tt][r] = apply_hidden_act<MODE, RELU>(acc[tt][r]);
             ASTAMP(2);  // sin
             // ---- hidden layers 1..nl-1: B operand = previous activations, straight from registers
             for (int l = 1; l < A.net.nl; ++l) {
@@ -506,7 +516,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) hid[tt][r] = MODE == MODE_EVAL_FAST ? fast_sin(30.0f * acc[tt][r]) : siren_act(acc[tt][r]);
+                    for (int r = 0; r < 16; ++r) hid[tt][r] = apply_hidden_act<MODE, RELU>(acc[tt][r]);
             }
             ASTAMP(3);  // hidden layers incl. their sin
             // ---- last layer: rows = channels
@@ -573,15 +583,15 @@ __global__ void k_sum_partials_mfma(const double* __restrict__ partial, int n, d
     if (lane == 0) *dst = s;
 }
 
-template <int NT, int MODE>
-static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s, bool whole_lds = false)
+template <int NT, int MODE, bool RELU>
+static int launch_apply_act(const ApplyArgs& A, int grid, hipStream_t s, bool whole_lds)
 {
     // whole_lds (a fit's background evaluation pass): the workgroup asks for 125 of the CU's 128 LDS granules of 1,280
     // bytes whatever it needs, so that the k_reduce_adam launches of the training chain beside it (4 granules) are
     // placed on the CUs the chain's own training step has just left, not next to this pass's waves -- there they took
     // 14.4 instead of 4.9 us (kernel trace of a fit alone, scripts/lone_timeline.py)
     const size_t lds_bytes = std::max((size_t)A.p.lds_floats * 4, whole_lds ? (size_t)125 * 1280 : (size_t)0);
-    auto kern = k_apply_mfma<NT, MODE>;
+    auto kern = k_apply_mfma<NT, MODE, RELU>;
     // the kernel may use the whole 160 KB of a CU's LDS: told to the runtime once per device and kernel (a cache of an
     // idempotent setting, not state a caller can observe)
     static std::atomic<unsigned long long> configured{0};
@@ -596,6 +606,13 @@ static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s, bool whole_
     kern<<<grid, APPLY_THREADS, lds_bytes, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
+}
+
+template <int NT, int MODE>
+static int launch_apply(const ApplyArgs& A, int grid, hipStream_t s, bool whole_lds = false)
+{
+    return A.net.act == LBDRN_ACT_RELU ? launch_apply_act<NT, MODE, true>(A, grid, s, whole_lds)
+                                       : launch_apply_act<NT, MODE, false>(A, grid, s, whole_lds);
 }
 
 #include "apply_wide.inc"

@@ -160,7 +160,8 @@ static int stream_lds_total(int LQ, int NL);
 
 static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan* out)
 {
-    if (net.act != LBDRN_ACT_SINE || net.bc != TBC || net.nl < 1 || net.nl > 3 || net.C > 16 || net.F < 1) return false;
+    if ((net.act != LBDRN_ACT_SINE && net.act != LBDRN_ACT_RELU) || net.bc != TBC || net.nl < 1 || net.nl > 3 || net.C > 16 || net.F < 1) return false;
+    if (net.act == LBDRN_ACT_RELU && (net.nl > 2 || train_kernel_choice() != 2)) return false;   // (ReLU: the streamed step and k_train_split; the nl = 3 tile kernel is the Sine network's)
     TrainPlan p;
     p.RP = (net.F + net.C + 3) / 4 * 4;
     p.LQ = 0;
@@ -172,6 +173,7 @@ static bool make_train_plan(const lbdrn_geom& g, const lbdrn_net& net, TrainPlan
             if (p.fm.Fe <= 4 * lq) { p.LQ = lq; break; }
         if (!p.LQ || (size_t)stream_lds_total(p.LQ, net.nl) * 4 > 160 * 1024) { kind = 0; p.LQ = 0; p.fm = FeatMap{net.F, 0, 0, 0}; }
     }
+    if (kind != 2 && net.act != LBDRN_ACT_SINE) return false;
     if (kind != 2)
         for (int lq : {16, 32, 52, 64})
             if (net.F <= 4 * lq && p.RP <= 4 * lq + 4) { p.LQ = lq; break; }
@@ -1130,11 +1132,26 @@ __global__ void __launch_bounds__(TRAIN_THREADS, 2) k_train_mfma(TrainArgs A)
 // for the canonical polynomials, 7 instructions against 31); the decode kernels keep the canonical arithmetic.
 // -DLBDRN_TRAIN_CANON_SINCOS puts the canonical pair back (A/B).
 __device__ __forceinline__ float train_sigmoid(float z) { return fast_sigmoid(z); }
+// The hidden activation of the fused steps and its derivative, as a template parameter of k_train_stream / k_train_split:
+// ACT = LBDRN_ACT_SINE: h = sin(30 z), dh/dz = 30 cos(30 z) (d holds the cosine);  LBDRN_ACT_RELU (torch.nn.ReLU, the
+// alternative the reference names at encode.py:75 / decode.py:108): h = z where z > 0, else 0; d = 1 / 0 in the slot of the
+// cosine and dz = dh where d != 0 (threshold_backward: what generic.hip's BackDx does)
+template <int ACT> __device__ __forceinline__ void train_act(float z, float& h, float& d);
+template <int ACT> __device__ __forceinline__ float train_act_back(float dh, float d)
+{
+    if constexpr (ACT == LBDRN_ACT_RELU) return d != 0.0f ? dh : 0.0f;
+    else return (dh * d) * 30.0f;
+}
 #ifdef LBDRN_TRAIN_CANON_SINCOS
 __device__ __forceinline__ void train_sincos(float x, float& sn, float& cs) { canon_sincos(x, sn, cs); }
 #else
 __device__ __forceinline__ void train_sincos(float x, float& sn, float& cs) { fast_sincos(x, sn, cs); }
 #endif
+template <int ACT> __device__ __forceinline__ void train_act(float z, float& h, float& d)
+{
+    if constexpr (ACT == LBDRN_ACT_RELU) { h = z > 0.0f ? z : 0.0f; d = z > 0.0f ? 1.0f : 0.0f; }
+    else train_sincos(30.0f * z, h, d);
+}
 
 // sum over the 64 lanes, same order every time, no LDS: rows of 16 by DPP shifts, then the four row totals
 // sum over each row of 16 lanes (DPP shifts, zero fill): lane 15 of a row holds the row's total
@@ -1232,15 +1249,22 @@ static int dispatch_nl(const TrainArgs& A, int nwg, hipStream_t s)
     return launch_train<LQ, 3>(A, nwg, s);
 }
 
-template <int LQ, int NL, int NT0C>
-static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
+template <int LQ, int NL, int NT0C, int ACT>
+static int launch_stream_act(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
-    auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD, NT0C>;
+    auto kern = k_train_stream<LQ, NL, LBDRN_STREAM_PD, NT0C, ACT>;
     static std::atomic<unsigned long long> configured{0};
     if (int rc = configure_lds_once(kern, A.p.wave_lds_floats * 4, configured)) return rc;
     kern<<<dim3((unsigned)nwg, (unsigned)count), STREAM_THREADS, (size_t)A.p.wave_lds_floats * 4, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
+}
+
+template <int LQ, int NL, int NT0C>
+static int launch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
+{
+    return A.net.act == LBDRN_ACT_RELU ? launch_stream_act<LQ, NL, NT0C, LBDRN_ACT_RELU>(A, nwg, count, s)
+                                       : launch_stream_act<LQ, NL, NT0C, LBDRN_ACT_SINE>(A, nwg, count, s);
 }
 
 static int dispatch_stream(const TrainArgs& A, int nwg, int count, hipStream_t s)
@@ -1279,16 +1303,23 @@ static bool split_available(const TrainPlan& p, const lbdrn_net& net)
     return p.wave == 2 && net.nl == 2 && ((p.LQ == 48 && p.NT0 == 12) || (p.LQ == 64 && p.NT0 == 16) || (p.LQ == 24 && p.NT0 == 6));
 }
 
-template <int LQ, int NT0C>
-static int launch_split(const TrainArgs& A, int nwg, int count, hipStream_t s)
+template <int LQ, int NT0C, int ACT>
+static int launch_split_act(const TrainArgs& A, int nwg, int count, hipStream_t s)
 {
-    auto kern = k_train_split<LQ, NT0C>;
+    auto kern = k_train_split<LQ, NT0C, ACT>;
     constexpr int bytes = split_lds(LQ).total * 4;
     static std::atomic<unsigned long long> configured{0};
     if (int rc = configure_lds_once(kern, bytes, configured)) return rc;
     kern<<<dim3((unsigned)nwg, (unsigned)count), WAVE_THREADS, (size_t)bytes, s>>>(A);
     LBDRN_LAUNCH_CHECK();
     return 0;
+}
+
+template <int LQ, int NT0C>
+static int launch_split(const TrainArgs& A, int nwg, int count, hipStream_t s)
+{
+    return A.net.act == LBDRN_ACT_RELU ? launch_split_act<LQ, NT0C, LBDRN_ACT_RELU>(A, nwg, count, s)
+                                       : launch_split_act<LQ, NT0C, LBDRN_ACT_SINE>(A, nwg, count, s);
 }
 
 static int dispatch_split(const TrainArgs& A, int nwg, int count, hipStream_t s)

@@ -1,5 +1,6 @@
-"""What the generic (LDS-tiled GEMM) kernels cost on the headline tile: the path every shape without a fused kernel takes --
-and the only one of lbdrn_net.act = LBDRN_ACT_RELU.  One 8 x 2048 x 2048 tile, two epochs + decode, per activation.
+"""What the generic (LDS-tiled GEMM) kernels cost on the headline tile -- the path every shape without a fused kernel takes --
+beside the fused kernels, for both hidden activations (lbdrn_net.act: Sine(30), and nn.ReLU, which has been a template
+argument of the fused kernels since round 6).  One 8 x 2048 x 2048 tile, two epochs + decode, per activation and path.
 usage: generic_path_timing.py [side=2048] [epochs=2]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,7 +14,8 @@ side = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda:0")
 img = ops.to_device_u16(synthetic_tile(1000, 8, side, side), dev)
-for act, path in (("sine", ops._lib.PATH_MFMA), ("sine", ops._lib.PATH_GENERIC), ("relu", ops._lib.PATH_AUTO)):
+for act, path in (("sine", ops._lib.PATH_MFMA), ("relu", ops._lib.PATH_MFMA), ("relu", ops._lib.PATH_AUTO),
+                  ("sine", ops._lib.PATH_GENERIC), ("relu", ops._lib.PATH_GENERIC)):
     cfg = FeatCfg(activation=act)
     for rep in range(2):
         torch.manual_seed(1)
