@@ -121,6 +121,8 @@ def config_key(a):
             return "embed"
         if not a.coords_embedding and a.bc in (64, 256):
             return f"bc{a.bc}"
+    if a.bands == 4 and a.K == 5 and a.D == 2 and a.nl == 2 and a.bc == 64 and not a.coords_embedding:
+        return "bands4"     # the reference's majority shape (run.sh:14-28: 9 of 13 images have four bands; F = 100)
     return None
 
 
@@ -138,8 +140,12 @@ def committed_profile(key, fits_per_launch):
     if key == "bc64" and fits_per_launch == 2:
         return cfgs.get("pair", {}), d
     prof = dict(cfgs.get(key, {}))
-    if fits_per_launch == 2 and cfgs.get(key + "_pair", {}).get("kernel_trace"):   # (counters of the single-fit launch, trace of the pair launch)
-        prof["kernel_trace"] = cfgs[key + "_pair"]["kernel_trace"]
+    if fits_per_launch == 2 and cfgs.get(key + "_pair"):   # the pair launch's own trace and, where a counter pass of it exists, counters
+        pc = cfgs[key + "_pair"]
+        for k in ("kernel_trace", "train", "reduce", "apply_eval", "timeline", "stamps"):
+            if pc.get(k):
+                prof[k] = pc[k]
+        prof["_pair_counters"] = bool(pc.get("train", {}).get("hbm_bytes_per_launch"))
     return prof, d
 
 
@@ -327,7 +333,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
         out["frac_of_occupied_cus"] = round(ach / (peak * out["cus_occupied"] / 256.0), 4)
     if prof and fused:
         tr, ap = prof.get("train", {}), prof.get("apply_eval", {})
-        pair = per_launch == 2 and key == "bc64"
+        pair = per_launch == 2 and (key == "bc64" or prof.get("_pair_counters"))
         out["traffic"] = tr.get("hbm_bytes_per_launch")
         out["traffic_algorithmic_bytes"] = B * 16 * (2 if pair else 1)
         out["traffic_note"] = ("counter values are per launch of a pair of fits (scripts/prof_pair.py)" if pair
@@ -345,6 +351,13 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
             out.update({"rocprof_kernel_us": round(r_us, 2), "rocprof_kernel_min_us": kt.get("train_min_us"),
                         "rocprof_source": kt.get("source"), "frac_rocprof": round(r_ach / peak, 4),
                         "frac": round(min(ach, r_ach) / peak, 4)})
+            if kt.get("timed_region_avg_us"):
+                # ... and the same kernel's average in the TIMED configuration (two chains of such launches in flight take turns
+                # on a chip either of them fills; the evaluation passes, row builds and permutations of the other fits share
+                # it too): what `frac` -- measured on the launch sequence alone -- is not
+                t_us = float(kt["timed_region_avg_us"]) + float(kt.get("timed_region_dw_avg_us") or 0.0)
+                out.update({"rocprof_kernel_us_timed_region": round(t_us, 2), "rocprof_timed_region_source": kt.get("timed_region_source"),
+                            "frac_timed_region": round(per_launch * step * B / (t_us * 1e-6) / 1e12 / peak, 4)})
         for extra in ("timeline", "stamps"):   # in-kernel evidence (s_memrealtime builds), committed as data
             if prof.get(extra):
                 out[extra] = prof[extra]
@@ -462,7 +475,7 @@ def lone_tile(codec, ops, tile, a, path, laps_n=3):
     return {"ms": ms, "encode_ms": enc, "decode_ms": dec, "fit": lone, "rec": rec}
 
 
-def side_leg(codec, ops, tiles, a, path, label, **over):
+def side_leg(codec, ops, tiles, a, path, label, with_single=False, **over):
     """A short leg of another BASELINE.json configuration inside the same call: warm-up tiles twice per in-flight stream,
     ONE timed region of `steps` tiles with `in_flight` progressing together, one tile alone (median of 3), the training
     launch's own duration (roofline_probe without the single-fit detour).  Same tiles, same method, same clock as the
@@ -488,10 +501,11 @@ def side_leg(codec, ops, tiles, a, path, label, **over):
                 and torch.equal(single["rec"], rec))
     px = b.height * b.width
     tile_flop = tile_flops(b, ops, fit, path)
-    roof = roofline_probe(codec, ops, fit, img_d, b, path, with_single=False)
+    roof = roofline_probe(codec, ops, fit, img_d, b, path, with_single=with_single)
     keep = ("kernel", "fits_per_launch", "kernel_us", "forward_backward_us", "weight_gradient_us", "marginal_us", "reduce_adam_us",
-            "unaccounted_us", "train_step_pair_us",
+            "unaccounted_us", "train_step_pair_us", "features_multiplied",
             "flop_per_launch", "achieved", "frac", "frac_live", "frac_rocprof", "rocprof_kernel_us", "rocprof_source",
+            "rocprof_kernel_us_timed_region", "frac_timed_region", "rocprof_timed_region_source", "single_fit_launch",
             "frac_of_occupied_cus", "apply_pass_ms", "apply_frac", "traffic", "mfma_busy_frac", "mfma_busy_frac_occupied_simds")
     out = {"workload": label, "steps": b.steps, "warmup": b.warmup, "tiles_in_flight": min(b.in_flight, b.steps),
            "tiles_per_launch": tiles_per_launch(b, ops, path), "repeats": 1,
@@ -501,11 +515,32 @@ def side_leg(codec, ops, tiles, a, path, label, **over):
            "end_to_end_frac": round(tile_flop * b.steps / elapsed / 1e12 / 157.3, 4),
            "single_tile_end_to_end_frac": round(tile_flop / (single["ms"] * 1e-3) / 1e12 / 157.3, 4),
            "timed_equals_lone": same, "recon_mse_last_tile": round(mse, 4),
-           "roofline": {k: roof[k] for k in keep if k in roof}}
+           "roofline": {k: roof[k] for k in keep if k in roof},
+           "accounting": accounting(b, roof, tiles_per_launch(b, ops, path), elapsed / b.steps * 1e3, single["decode_ms"])}
     del single, done, fit, rec
     torch.cuda.empty_cache()      # the next leg's workspaces have other sizes
     out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
     return out
+
+
+def accounting(a, roof, fits_per_launch, ms_per_tile, decode_ms):
+    """Why a tile takes what it takes, as an equation over measured kernel durations.  With several
+    fits in flight every launch below wants every CU, so they take turns and their durations ADD:
+        tile ~= (steps / fits per launch) x training launch  +  evaluation passes  +  decode pass  +  rest
+    `training launch` = the launch's own duration (roofline.kernel_us: the launch sequence alone), `rest` = what is left of
+    the measured tile: the row build, the permutations, reduce / Adam launches that found no room beside another chain's
+    training launch, ramps.  A faster training launch ALONE moves the tile only by its share of this sum."""
+    px = a.height * a.width
+    steps = a.epochs * ((px + a.bs - 1) // a.bs)
+    launches = steps / max(fits_per_launch, 1)
+    evals = a.epochs if a.epochs > 1 else 0
+    train_ms = launches * roof.get("kernel_us", 0.0) * 1e-3
+    eval_ms = evals * roof.get("apply_pass_ms", 0.0)
+    known = train_ms + eval_ms + decode_ms
+    return {"training_launches_per_tile": launches, "training_ms": round(train_ms, 2), "evaluation_passes_ms": round(eval_ms, 2),
+            "decode_ms": round(decode_ms, 2), "rest_ms": round(ms_per_tile - known, 2), "measured_ms_per_tile": round(ms_per_tile, 2),
+            "training_share": round(train_ms / ms_per_tile, 3),
+            "equation": "measured_ms_per_tile = training_launches_per_tile x roofline.kernel_us + epochs x roofline.apply_pass_ms + decode_ms + rest_ms"}
 
 
 def launch_ranks(a):
@@ -720,11 +755,17 @@ def main():
         out["roofline"]["end_to_end_frac"] = round(tile_flop * a.steps / elapsed / 1e12 / 157.3, 4)
         out["roofline"]["single_tile_end_to_end_frac"] = round(tile_flop / (single["ms"] * 1e-3) / 1e12 / 157.3, 4)
         out["roofline"].update(hbm_fields(a, elapsed / a.steps, config_key(a), out["config"]["tiles_per_launch"]))
+        out["accounting"] = accounting(a, out["roofline"], out["config"]["tiles_per_launch"], elapsed / a.steps * 1e3, single["decode_ms"])
         del single, lone, lone_rec
         if world == 1 and not a.no_other_configs and config_key(a) == "bc64" and a.height == 2048 and a.width == 2048 \
                 and a.path == "auto":
-            # BASELINE.json configs[2] and configs[4], a short leg each in the same call (the headline above is unchanged)
+            # BASELINE.json configs[2] and configs[4], and the reference's own majority shape -- four bands (9 of the 13 images of
+            # run.sh:14-28), the first four bands of the resident tiles --, a short leg each in the same call (the headline above is
+            # unchanged)
             out["other_configs"] = {
+                "bands4": side_leg(codec, ops, [t[:4] for t in tiles], a, path, with_single=True, bands=4, in_flight=4, steps=8, warmup=4,
+                                   label="the reference's 4-band shape (GF-2 / GF6-PMS: run.sh:14-28), K=5 D=2 bc=64 nl=2, F = 100 "
+                                         "(k_train_stream<24,2,3,6> in flight, k_train_split<24,6> alone)"),
                 "bc256": side_leg(codec, ops, tiles, a, path, bc=256, in_flight=codec.default_in_flight(a.bands, a.height, a.width, a.K, a.D, 256, a.nl),
                                   steps=6, warmup=3,   # (codec.default_in_flight: 3 chains at bc >= 128 -- 2: 352, 3: 343, 4: 386, 6: 345 ms per tile)
                                   label="BASELINE.json configs[2]: the same tile, bc = 256 (k_train_half + k_dw_wide / k_apply_wide)"),

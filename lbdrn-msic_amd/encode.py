@@ -53,8 +53,42 @@ def train(args, img=None):
     return report_and_pack(args, res)
 
 
-def report_and_pack(args, res):
-    """The records train() logs for one finished fit, and its two payloads."""
+class BasePayloadsAhead:
+    """The JPEG 2000 MSB payloads of an image's tiles, coded WHILE the GPU fits (round 6).  The MSB planes are `tile >> K`
+    (ref LBDRNdataset.py:95): known the moment the raster is read, long before the fit ends -- and the reference's own format
+    (LBDRN_BASE_CODEC=jp2: what `gdal_translate -of JP2OpenJPEG` writes, ref encode.py:137) costs 0.8-1.3 s of eight host
+    threads per 8 x 2048^2 tile against a 0.1 s fit.  One background thread codes the tiles in order, OpenJPEG's own worker
+    threads inside each call (lbdrn_jp2_set_threads; the ctypes call releases the interpreter); report_and_pack takes the
+    finished payload -- the same bytes as coding it afterwards -- or waits for it."""
+
+    def __init__(self, tiles, K):
+        import threading
+        self.payloads, self.errors, self.seconds = {}, {}, {}
+        self._done = {k: threading.Event() for k in range(len(tiles))}
+
+        def work():
+            for k, tile in enumerate(tiles):
+                t0 = time.time()
+                try:
+                    msb = np.asarray(tile).reshape((-1,) + tile.shape[-2:]) >> K
+                    msb = msb.astype(np.uint8) if int(msb.max()) <= 255 else msb.astype(np.uint16)      # LBDRNdataset.py:100
+                    self.payloads[k] = container.encode_base(msb, codec="jp2")
+                except Exception as e:   # (reported where the payload is asked for)
+                    self.errors[k] = e
+                self.seconds[k] = time.time() - t0
+                self._done[k].set()
+        self._thread = threading.Thread(target=work, name="lbdrn-jp2-ahead", daemon=True)
+        self._thread.start()
+
+    def take(self, k):
+        self._done[k].wait()
+        if k in self.errors:
+            raise self.errors[k]
+        return self.payloads.pop(k)
+
+
+def report_and_pack(args, res, base_ahead=None):
+    """The records train() logs for one finished fit, and its two payloads.  base_ahead: () -> the MSB payload coded meanwhile."""
     filename = os.path.splitext(os.path.basename(args.path))[0]
     logger.log.info("total_params: {}".format(res.params.size))
     for epoch, mse, improved in res.epoch_mse:
@@ -67,7 +101,11 @@ def report_and_pack(args, res):
     logger.log.info(f"nn: {len(nn_payload)} bytes, bpsp={len(nn_payload) * 8 / res.n_subpixels}")
     # ref encode.py:137 (gdal_translate to JP2): here the plane is coded where the fit left it, in HBM;
     # uint8 when it fits, like the reference's MSB raster (LBDRNdataset.py:100)
-    if BASE_CODEC == "LBB2":
+    if base_ahead is not None:
+        t0 = time.time()
+        base_payload = base_ahead()
+        logger.log.info(f"MSB payload ({BASE_CODEC}) coded beside the fit; waited {time.time() - t0:.3f}s more for it")
+    elif BASE_CODEC == "LBB2":
         base_payload = container.encode_base(res.msb_device, device=DEVICE, as_uint8=res.msb_max <= 255)
     else:
         base_payload = container.encode_base(_host_msb(res), codec=BASE_CODEC)
@@ -186,18 +224,23 @@ def main(argv=None, shard_tiles=None):
             path = f"{args.output_dir}/tile_{i}_{j}.tif"
             tile = np.ascontiguousarray(img[:, y0:y0 + h, x0:x0 + w])
         jobs.append((path, tile))
+    # the reference's MSB format is host work that needs nothing from the fit: it starts now (LBDRN_JP2_AHEAD=0: afterwards, as before)
+    ahead = None
+    if jobs and BASE_CODEC.lower() in ("jp2", "jpeg2000", "jp2openjpeg") and os.environ.get("LBDRN_JP2_AHEAD", "1") != "0":
+        ahead = BasePayloadsAhead([tile for _, tile in jobs], args.K)
     results = train_tiles(args, jobs, [draws[t] for t in mine]) if jobs else []
     fitted = []   # (tile index, nn payload, MSB payload, captured log records or None)
-    for t, (path, _), res in zip(mine, jobs, results):
+    for k, (t, (path, _), res) in enumerate(zip(mine, jobs, results)):
         args.path = path
+        take = (lambda k=k: ahead.take(k)) if ahead is not None else None
         if world > 1:
             with logger.capture() as lines:
                 logger.log.info(args)
-                nn, base = report_and_pack(args, res)
+                nn, base = report_and_pack(args, res, take)
         else:
             lines = None
             logger.log.info(args)
-            nn, base = report_and_pack(args, res)
+            nn, base = report_and_pack(args, res, take)
         fitted.append((t, nn, base, lines))
     gathered = shard.gather_to_root(fitted) if world > 1 else [fitted]
     if rank == 0:

@@ -199,8 +199,39 @@ def memory_limited_in_flight(images, wanted, K, D, base_channel, num_layers, bat
 # What the two launches that share the chip during a lone fit's background evaluation pass achieve, as fractions of the
 # f32-MFMA peak (157.3 TFLOP/s) -- measured, DESIGN.md section 4: the evaluation pass on the whole chip (it runs on half of
 # it in the background: twice as long), and k_train_stream's single-fit launch on its 128 CUs, plus the step's two kernel
-# boundaries and its reduce / Adam launch.
+# boundaries and its reduce / Adam launch.  These are the FIRST GUESS only (round 6): every lone fit times its first background
+# pass and the steps beside it with events it never waits for, and the next fit of that shape in the process draws the
+# line where the measurement puts it (_calibrated_head) -- constants that go stale with a kernel change now cost the first
+# fit of a process a few per cent, not every fit (tests/test_gpu_train_paths.py holds the guess to the measurement).
 EVAL_PASS_FRAC_OF_PEAK, HALF_CHIP_STEP_FRAC_OF_PEAK, HALF_CHIP_STEP_OVERHEAD_S, PEAK_FLOPS = 0.65, 0.26, 5.0e-6, 157.3e12
+_HEAD_LOCK = threading.Lock()
+_HEAD_MEASURED = {}     # shape key -> steps that last as long as the background pass beside them, as measured
+_HEAD_PENDING = {}      # shape key -> ((pass start, pass end, head start, head end) events, head steps) of a fit that has been enqueued
+
+
+def _head_key(dev, net, n_pixels, batch_size):
+    return (dev.index, int(net.F), int(net.bc), int(net.C), int(net.nl), int(net.act), int(n_pixels), int(batch_size))
+
+
+def _calibrated_head(key, guess, steps_per_epoch):
+    """The head count of `key`: the model's guess until a fit of that shape has run, then what its events say -- the head
+    scaled by pass time / head time, kept within [guess / 2, 2 guess].  Never waits: events that have not completed yet are
+    looked at by a later fit."""
+    with _HEAD_LOCK:
+        pend = _HEAD_PENDING.get(key)
+        if pend is not None and pend[0][1].query() and pend[0][3].query():
+            (p0, p1, h0, h1), head = pend
+            del _HEAD_PENDING[key]
+            t_pass, t_head = p0.elapsed_time(p1), h0.elapsed_time(h1)
+            if t_pass > 0 and t_head > 0 and head > 0:
+                _HEAD_MEASURED[key] = int(round(min(max(head * t_pass / t_head, 0.5 * guess), 2.0 * guess)))
+        return max(0, min(steps_per_epoch, _HEAD_MEASURED.get(key, guess)))
+
+
+def head_calibration():
+    """{shape key: measured head steps} of this process so far (diagnostics, tests)."""
+    with _HEAD_LOCK:
+        return dict(_HEAD_MEASURED)
 
 
 def background_steps(steps_per_epoch, net=None, n_pixels=None, batch_size=None):
@@ -293,6 +324,10 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
     if side is not None:
         side.wait_stream(main)       # the workspaces and the planes above are ready
     adam_steps = 0
+    # (the first background pass and the steps beside it are timed with events nobody waits for: _calibrated_head)
+    hkey = _head_key(dev, net, N, batch_size)
+    cal_epoch = eval_epochs[0] if eval_epochs else 0
+    cal_events = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (side is not None and alone and cal_epoch + 1 <= epochs) else None
     try:
         for e in range(1, epochs + 1):
             perm = stream.get(e).to(dev, non_blocking=True)                  # a4 (already on the device)
@@ -300,12 +335,23 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
             # it go out WITHOUT the alone hint -- the half-chip launch that fits on the other half (k_train_stream) --, the
             # rest of the epoch with it (k_train_split, every CU).  Same numbers either way (lbdrn_hip.h: the hint
             # changes no bit), so where the line is drawn is a matter of time only.
-            head = background_steps(steps_per_epoch, net, N, batch_size) if (side is not None and alone and e - 1 in eval_epochs) else 0
+            head = 0
+            if side is not None and alone and e - 1 in eval_epochs:
+                head = background_steps(steps_per_epoch, net, N, batch_size)
+                if "LBDRN_LONE_HEAD_FRAC" not in os.environ:
+                    head = _calibrated_head(hkey, head, steps_per_epoch)
             for lo, hi, hint in ((0, head, False), (head, steps_per_epoch, alone)):
                 if hi > lo:
+                    timed = cal_events is not None and lo == 0 and head > 0 and e == cal_epoch + 1
+                    if timed:
+                        cal_events[2].record(main)
                     ops.train_epoch(geom, net, img_d, msb_d, perm[lo * batch_size:hi * batch_size], batch_size, params, exp_avg,
                                     exp_avg_sq, adam_steps + lo, lrs[e - 1], losses[e - 1][lo:hi] if keep_losses else None, path,
                                     train_ws, alone=hint)
+                    if timed:
+                        cal_events[3].record(main)
+                        with _HEAD_LOCK:
+                            _HEAD_PENDING[hkey] = (cal_events, head)
             adam_steps += steps_per_epoch
             if e in eval_epochs:                                              # encode.py:104-117
                 k = eval_epochs.index(e)
@@ -314,8 +360,12 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
                     side.wait_stream(main)
                 with torch.cuda.stream(side if side is not None else main):
                     background = side is not None and e != epochs      # nothing trains beside the last pass
+                    if cal_events is not None and e == cal_epoch:
+                        cal_events[0].record()
                     sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background,
                                        fast=fast_evaluation())   # a9
+                    if cal_events is not None and e == cal_epoch:
+                        cal_events[1].record()
                     mses[k:k + 1].copy_((sse / float(N * C)).float())
                 out.evaluated.append(e)
     finally:

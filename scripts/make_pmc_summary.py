@@ -35,12 +35,16 @@ for f in sorted(os.listdir(src)):
     if f.endswith((".csv", ".json")) and not f.startswith("."):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f"{tag}_{f}"))
 # (apply_eval: the evaluation pass as a fit runs it -- MODE_EVAL_FAST = 2; the canonical MODE_EVAL = 1 pass where a run used it)
-KERNELS = {"bc64": {"train": "k_train_stream<48", "train_split": "k_train_split<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>",
+KERNELS = {"bc64": {"train": "k_train_stream<48", "train_split": "k_train_split<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2", "apply_decode": "k_apply_mfma<2, 0",
                     "build_rows": "k_build_rows_tiled"},
            "bc256": {"train": "k_train_half", "dw": "k_dw_wide", "reduce": "k_reduce_adam", "apply_eval": "k_apply_wide<16, 2, 2>", "apply_decode": "k_apply_wide<16, 2, 0>"},
-           "embed": {"train": "k_train_stream<64", "train_split": "k_train_split<64", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>", "apply_decode": "k_apply_mfma<2, 0>"},
+           "embed": {"train": "k_train_stream<64", "train_split": "k_train_split<64", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2", "apply_decode": "k_apply_mfma<2, 0"},
            # the launches of a PAIR of bc64 fits stepping side by side (scripts/prof_pair.py): 2 x 128 workgroups, every CU
-           "pair": {"train": "k_train_stream<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2>"}}
+           "pair": {"train": "k_train_stream<48", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2"},
+           # the reference's 4-band shape (F = 100: run.sh:14-28), one fit alone and the pair launch
+           "bands4": {"train": "k_train_stream<24", "train_split": "k_train_split<24", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2", "apply_decode": "k_apply_mfma<2, 0",
+                      "build_rows": "k_build_rows_tiled"},
+           "bands4_pair": {"train": "k_train_stream<24", "reduce": "k_reduce_adam", "apply_eval": "k_apply_mfma<2, 2"}}
 # MI355X_MICROARCH.md, HBM: "on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read (16 B per
 # lane, global_load and buffer_load ... lds alike)" -- so the doubling applies to the kernels whose fetches ARE such reads
 # (rows by LDS-DMA, fragments / weights / slabs as 16-byte loads) and NOT to the apply kernels, which fetch two uint16 planes
@@ -76,7 +80,12 @@ def load_json(name):
 
 # configuration -> the kernel-trace summary in which its training launch runs ALONE on the device (one chain)
 TRACE = {"bc64": "kernel_stats_one_in_flight.csv", "pair": "kernel_stats_pair_alone.csv", "bc256": "kernel_stats_alone_bc256.csv",
-         "embed": "kernel_stats_alone_embed.csv", "embed_pair": "kernel_stats_pair_alone_embed.csv"}
+         "embed": "kernel_stats_alone_embed.csv", "embed_pair": "kernel_stats_pair_alone_embed.csv",
+         "bands4": "kernel_stats_alone_bands4.csv", "bands4_pair": "kernel_stats_pair_alone_bands4.csv"}
+# ... and the summary of the TIMED configuration (bench.py's default run: two chains of pair launches in flight), whose
+# average of the same kernel is longer -- the chains take turns on a chip either of them fills
+TRACE_TIMED = {"pair": "kernel_stats_four_in_flight.csv", "embed_pair": "kernel_stats_embed.csv", "bands4_pair": "kernel_stats_bands4.csv",
+               "bc256": "kernel_stats_bc256.csv"}
 for cfg, kernels in KERNELS.items():
     fetch, write = load(f"pmc_{cfg}_FETCH_SIZE.csv"), load(f"pmc_{cfg}_WRITE_SIZE.csv")
     sqa, sqb = load(f"sq_a_{cfg}.csv"), load(f"sq_b_{cfg}.csv")
@@ -129,6 +138,14 @@ for cfg, csv_name in list(TRACE.items()) + [("split", None), ("split_embed", Non
         d = trace_avg(csv_name, "k_dw_wide") if cfg == "bc256" else None
         if d:
             cout["kernel_trace"].update(dw_avg_us=d[0], dw_min_us=d[1])
+        tt = trace_avg(TRACE_TIMED[cfg], KERNELS.get(cfg, KERNELS["embed"])["train"]) if cfg in TRACE_TIMED else None
+        if tt:
+            cout["kernel_trace"].update(timed_region_avg_us=tt[0], timed_region_min_us=tt[1], timed_region_calls=tt[2],
+                                        timed_region_source=f"profiles/{tag}_{TRACE_TIMED[cfg]}")
+            if cfg == "bc256":
+                td = trace_avg(TRACE_TIMED[cfg], "k_dw_wide")
+                if td:
+                    cout["kernel_trace"].update(timed_region_dw_avg_us=td[0])
         sp = trace_avg(csv_name, KERNELS.get(cfg, {}).get("train_split", "k_train_split<none"))
         if sp:   # the every-CU launch of a lone fit (most of the steps of such a trace; the rest go out on the half-chip launch above)
             cout["kernel_trace"].update(split_avg_us=sp[0], split_min_us=sp[1], split_calls=sp[2], split_kernel=sp[3])

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Profile pass of a round, run ON the GPU box (gpurun): scripts/profile_round.sh TAG [kt|cfg|pmc|sq ...]
 #   kta  the training launch of bc256 / embed / embed pairs alone on the device; ink  in-kernel stamps + timeline JSON
+#   b4   the reference's 4-band shape (F = 100): bench.py --bands 4 with four in flight, one fit alone, one pair alone
 #   kt   rocprofv3 --kernel-trace --stats of bench.py with one fit in flight and with the default (four, as two pairs),
 #        and of one pair of fits alone (scripts/prof_pair.py)
 #   cfg  the same for BASELINE.json configs[2] (bc = 256) and configs[4] (USE_COORDINATES + EMBEDDING)
@@ -19,7 +20,7 @@ summarise() { # dir out-csv script [filters]
   if [ -n "$DB" ]; then python $3 $DB $2 ${@:4} > ${2%.csv}.txt 2>&1; else echo "no database in $1" > ${2%.csv}.txt; fi
   rm -rf $1
 }
-declare -A PROG=( [bc64]="scripts/prof_fit.py 2048 64 4" [bc256]="scripts/prof_fit.py 2048 256 2" [embed]="scripts/prof_fit.py 2048 64 4 embed" [pair]="scripts/prof_pair.py 2048 3" )
+declare -A PROG=( [bc64]="scripts/prof_fit.py 2048 64 4" [bc256]="scripts/prof_fit.py 2048 256 2" [embed]="scripts/prof_fit.py 2048 64 4 embed" [pair]="scripts/prof_pair.py 2048 3" [bands4]="scripts/prof_fit.py 2048 64 4 bands4" [bands4_pair]="scripts/prof_pair.py 2048 3 bands4" )
 CFGS=${CFGS:-bc64 bc256 embed pair}
 for W in $WHAT; do case $W in
 kt)
@@ -36,6 +37,13 @@ kta)  # the training launch of every configuration ALONE on the device (one chai
   summarise $OUT/kta_embed $OUT/kernel_stats_alone_embed.csv scripts/rocprof_kernel_stats.py
   rocprofv3 --kernel-trace --stats -d $OUT/kta_embedp -o run -- python3 scripts/prof_pair.py 2048 3 embed > $OUT/pair_alone_embed.txt 2> $OUT/kta_embedp.err
   summarise $OUT/kta_embedp $OUT/kernel_stats_pair_alone_embed.csv scripts/rocprof_kernel_stats.py ;;
+b4)
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_b4 -o run -- python3 bench.py --no-cpu-baseline --no-other-configs --bands 4 --repeats 1 > $OUT/bench_bands4.json 2> $OUT/kt_b4.err
+  summarise $OUT/kt_b4 $OUT/kernel_stats_bands4.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/kta_b4 -o run -- python3 scripts/prof_fit.py 2048 64 3 bands4 > $OUT/alone_bands4.txt 2> $OUT/kta_b4.err
+  summarise $OUT/kta_b4 $OUT/kernel_stats_alone_bands4.csv scripts/rocprof_kernel_stats.py
+  rocprofv3 --kernel-trace --stats -d $OUT/kta_b4p -o run -- python3 scripts/prof_pair.py 2048 3 bands4 > $OUT/pair_alone_bands4.txt 2> $OUT/kta_b4p.err
+  summarise $OUT/kta_b4p $OUT/kernel_stats_pair_alone_bands4.csv scripts/rocprof_kernel_stats.py ;;
 ink)  # in-kernel stamps / timeline as JSON (diagnostic builds; scripts/collect_inkernel.py)
   python3 scripts/collect_inkernel.py $TAG > $OUT/inkernel.log 2>&1; echo "ink rc=$?" >> $OUT/status.txt ;;
 cfg)

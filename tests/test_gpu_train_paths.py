@@ -757,3 +757,31 @@ def test_the_reference_scene_size_through_the_clis(dev, tmp_path):
         os.remove(sub / "scene_recon.tif")
         del rec
     assert abs(sizes[1] - sizes[3]) < 0.02 * sizes[1], sizes       # (the MSB planes dominate; nine small networks instead of one)
+
+
+@pytest.mark.parametrize("bands", (8, 4))
+def test_lone_fit_schedule_guess_is_close_to_its_measurement(dev, bands):
+    """A lone fit steps the head of an epoch on the half-chip launch beside the previous epoch's background evaluation pass
+    and the rest on every CU (codec.fit_device).  Where the line is drawn is a matter of time only (no bit depends on it:
+    test_alone_hint_changes_no_number) -- first by a model with two measured constants (codec.background_steps), from the
+    second fit of a shape on by the fit's own events (codec._calibrated_head).  This holds the constants to the measurement,
+    so that they cannot go stale silently when a kernel changes: full-size tile, both band counts."""
+    if os.environ.get("LBDRN_LONE_HEAD_FRAC") is not None or codec.device_shared():
+        pytest.skip("the schedule is overridden by the environment")
+    img = ops.to_device_u16(synthetic_tile(0, bands, 2048, 2048), dev)
+    K, D, bc, nl, bs, epochs = 5, 2, 64, 2, 8192, 3
+    fits = []
+    for _ in range(3):
+        torch.manual_seed(19920517)
+        fits.append(codec.fit_device(img, K, D, bc, nl, 1e-3, bs, epochs))
+        torch.cuda.synchronize()
+    net = fits[0].net
+    steps = (2048 * 2048 + bs - 1) // bs
+    guess = codec.background_steps(steps, net, 2048 * 2048, bs)
+    got = codec.head_calibration().get(codec._head_key(dev, net, 2048 * 2048, bs))
+    assert got is not None, "no fit of this shape left a measurement"
+    assert 0.1 * steps < guess < 0.5 * steps
+    assert 0.6 * guess <= got <= 1.6 * guess, (guess, got)
+    # ... and wherever the line was drawn, the fits are one fit
+    for f in fits[1:]:
+        assert torch.equal(f.best_params.view(torch.int32), fits[0].best_params.view(torch.int32))

@@ -174,3 +174,14 @@ def test_cli_round_trip_with_the_jpeg2000_payload(jp2, dev, tmp_path):
         other = re.search(r"MSB as (jp2|LBB2): (\d+) bytes: bpsp=", log)
         assert other and other.group(1) == ("LBB2" if codec_name == "jp2" else "jp2") and len(re.findall(r"MSB: \d+ bytes", log)) == 1
     assert np.array_equal(recs["jp2"], recs["LBB2"]) and np.array_equal(recs["jp2"] >> 5, img >> 5)
+    # the JP2 payloads are coded on a host thread WHILE the GPU fits (encode.BasePayloadsAhead, round 6): the same .bin byte
+    # for byte as coding them after the fits (LBDRN_JP2_AHEAD=0), one tile or four
+    assert "coded beside the fit" in (tmp_path / "jp2" / "tile_r1_K5_bc64_nl2_D2_prec16_lr0.001_bs256_e2" / "encode.txt").read_text()
+    bins = {}
+    for ahead in ("1", "0"):
+        env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "lbdrn-msic_amd"), LBDRN_BASE_CODEC="jp2", LBDRN_JP2_AHEAD=ahead)
+        out = tmp_path / f"sr2_ahead{ahead}"
+        subprocess.run([sys.executable, os.path.join(ROOT, "lbdrn-msic_amd", "encode.py"), "-i", str(src), "-o", str(out),
+                        "-K", "5", "-D", "2", "-bs", "256", "-e", "2", "-sr", "2"], check=True, env=env, capture_output=True)
+        bins[ahead] = (out / "tile_r2_K5_bc64_nl2_D2_prec16_lr0.001_bs256_e2" / "tile.bin").read_bytes()
+    assert bins["1"] == bins["0"] and len(bins["1"]) > 1000
