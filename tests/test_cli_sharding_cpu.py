@@ -45,7 +45,7 @@ def _stub_train_tiles(args, tiles, draws):
     return out
 
 
-def _stub_report(args, res):
+def _stub_report(args, res, base_ahead=None):
     import logger
     nn, base = res
     logger.log.info(f"nn: {len(nn)} bytes, bpsp=0.5")
