@@ -3,6 +3,7 @@
  * (encode.py:137; decode.py:69-73).  Host code; built by csrc/build.py when openjpeg.h is found. */
 #include <openjpeg.h>
 #include <stdarg.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -18,16 +19,33 @@ static void set_err(const char *fmt, ...)
     va_end(ap);
 }
 const char *lbdrn_jp2_last_error(void) { return g_err; }
-/* worker threads OpenJPEG may use inside one call (code blocks are independent: the bytes do not depend on it) */
-static int g_threads = 0;
+/* worker threads OpenJPEG may use inside one call (code blocks are independent: the bytes do not depend on it); read by
+ * calls on any thread while another thread may set it */
+static atomic_int g_threads = 0;
 int lbdrn_jp2_set_threads(int32_t n)
 {
-    const int old = g_threads;
-    if (n >= 0 && n <= 256) g_threads = n;
-    return old;
+    if (n >= 0 && n <= 256) return atomic_exchange(&g_threads, (int)n);
+    return atomic_load(&g_threads);
 }
 
-static void on_error(const char *msg, void *u) { (void)u; set_err("openjpeg: %s", msg); }
+/* OpenJPEG reports an error on whichever thread met it -- with worker threads, a code-block worker whose thread-local
+ * g_err nobody reads.  Every call therefore hands the handler a context of its own: the FIRST message of
+ * the call is kept (first writer wins, an atomic flag), and the calling thread copies it into its g_err when the call
+ * ends (take_err). */
+typedef struct { atomic_flag taken; char msg[480]; } err_ctx;
+static void on_error(const char *msg, void *u)
+{
+    err_ctx *e = (err_ctx *)u;
+    if (e && !atomic_flag_test_and_set(&e->taken)) {
+        snprintf(e->msg, sizeof e->msg, "%s", msg ? msg : "");
+        for (size_t k = strlen(e->msg); k > 0 && (e->msg[k - 1] == '\n' || e->msg[k - 1] == '\r'); --k) e->msg[k - 1] = 0;
+    }
+}
+static void take_err(err_ctx *e, const char *fallback)   /* on the calling thread, after the codec's workers have been joined */
+{
+    if (e->msg[0]) set_err("openjpeg: %s", e->msg);
+    else if (!g_err[0]) set_err("%s", fallback);
+}
 static void on_quiet(const char *msg, void *u) { (void)msg; (void)u; }
 
 /* ---- a growable / read-only memory stream */
@@ -153,25 +171,28 @@ int lbdrn_jp2_encode(const uint16_t *planes, int32_t C, int32_t H, int32_t W, in
     }
     int rc = -3;
     mem_t mem = {NULL, 0, 0, 0, 1};
+    err_ctx ectx = {ATOMIC_FLAG_INIT, {0}};
+    const int threads = atomic_load(&g_threads);
     opj_codec_t *codec = opj_create_compress(OPJ_CODEC_JP2);
     opj_stream_t *st = NULL;
+    g_err[0] = 0;
     if (!codec) { set_err("opj_create_compress failed"); goto done; }
-    opj_set_error_handler(codec, on_error, NULL);
+    opj_set_error_handler(codec, on_error, &ectx);
     opj_set_warning_handler(codec, on_quiet, NULL);
     opj_set_info_handler(codec, on_quiet, NULL);
-    if (!opj_setup_encoder(codec, &prm, img)) { if (!g_err[0]) set_err("opj_setup_encoder failed"); goto done; }
-    if (g_threads > 1 && opj_has_thread_support()) (void)opj_codec_set_threads(codec, g_threads);   /* (between setup and start) */
+    if (!opj_setup_encoder(codec, &prm, img)) { take_err(&ectx, "opj_setup_encoder failed"); goto done; }
+    if (threads > 1 && opj_has_thread_support()) (void)opj_codec_set_threads(codec, threads);   /* (between setup and start) */
     st = open_stream(&mem, 0);
     if (!st) { set_err("opj_stream_create failed"); goto done; }
-    g_err[0] = 0;
     if (!opj_start_compress(codec, img, st) || !opj_encode(codec, st) || !opj_end_compress(codec, st)) {
-        if (!g_err[0]) set_err("openjpeg: compression failed");
+        rc = -4;   /* (the message is taken below, once the codec -- and with it its worker threads -- is gone) */
         goto done;
     }
     rc = 0;
 done:
     if (st) opj_stream_destroy(st);
     if (codec) opj_destroy_codec(codec);
+    if (rc == -4) { take_err(&ectx, "openjpeg: compression failed"); rc = -3; }
     opj_image_destroy(img);
     if (rc) { free(mem.data); return rc; }
     *out = mem.data;
@@ -199,16 +220,19 @@ static int decode_impl(const uint8_t *buf, size_t bytes, uint16_t *planes, int32
     opj_stream_t *st = NULL;
     opj_image_t *img = NULL;
     int rc = -3;
+    err_ctx ectx = {ATOMIC_FLAG_INIT, {0}};
+    const int threads = atomic_load(&g_threads);
+    const char *fallback = NULL;   /* rc == -3 with a fallback: an OpenJPEG call failed; its message is taken behind `done` */
     if (!codec) { set_err("opj_create_decompress failed"); return -3; }
-    opj_set_error_handler(codec, on_error, NULL);
+    opj_set_error_handler(codec, on_error, &ectx);
     opj_set_warning_handler(codec, on_quiet, NULL);
     opj_set_info_handler(codec, on_quiet, NULL);
     g_err[0] = 0;
-    if (!opj_setup_decoder(codec, &prm)) { if (!g_err[0]) set_err("opj_setup_decoder failed"); goto done; }
-    if (g_threads > 1 && opj_has_thread_support()) (void)opj_codec_set_threads(codec, g_threads);
+    if (!opj_setup_decoder(codec, &prm)) { fallback = "opj_setup_decoder failed"; goto done; }
+    if (threads > 1 && opj_has_thread_support()) (void)opj_codec_set_threads(codec, threads);
     st = open_stream(&mem, 1);
     if (!st) { set_err("opj_stream_create failed"); goto done; }
-    if (!opj_read_header(st, codec, &img) || !img) { if (!g_err[0]) set_err("openjpeg: cannot read the header"); goto done; }
+    if (!opj_read_header(st, codec, &img) || !img) { fallback = "openjpeg: cannot read the header"; goto done; }
     {
         const int32_t c = (int32_t)img->numcomps, w = (int32_t)(img->x1 - img->x0), h = (int32_t)(img->y1 - img->y0);
         int32_t prec = 0;
@@ -223,7 +247,7 @@ static int decode_impl(const uint8_t *buf, size_t bytes, uint16_t *planes, int32
             goto done;
         }
         if (c != *C || h != *H || w != *W) { set_err("stream is %d x %d x %d, caller expected %d x %d x %d", c, h, w, *C, *H, *W); rc = -1; goto done; }
-        if (!opj_decode(codec, st, img) || !opj_end_decompress(codec, st)) { if (!g_err[0]) set_err("openjpeg: decoding failed"); goto done; }
+        if (!opj_decode(codec, st, img) || !opj_end_decompress(codec, st)) { fallback = "openjpeg: decoding failed"; goto done; }
         const size_t n = (size_t)h * w;
         for (int k = 0; k < c; ++k) {
             const OPJ_INT32 *d = img->comps[k].data;
@@ -236,7 +260,8 @@ static int decode_impl(const uint8_t *buf, size_t bytes, uint16_t *planes, int32
 done:
     if (img) opj_image_destroy(img);
     if (st) opj_stream_destroy(st);
-    opj_destroy_codec(codec);
+    opj_destroy_codec(codec);          /* joins the codec's worker threads: whatever they reported is in ectx by now */
+    if (fallback) take_err(&ectx, fallback);
     return rc;
 }
 

@@ -21,6 +21,7 @@ from LBDRNdataset import tile_windows, write_tiff_with_gdal
 
 DEVICE = "cuda:0"
 K = D = bc = nl = None  # set from the header; test() reads them like the reference's does
+ACTIVATION = None       # "relu" / "sine" where the header names the hidden activation (container.header_activation), else None
 
 
 def read_image_header(bitstream):
@@ -34,6 +35,8 @@ def test(bitstream, dirname, filename, nn_bytes, base_bytes, write=True):
     base_payload, bitstream = bitstream[:base_bytes], bitstream[base_bytes:]
     base = container.decode_base(base_payload, device=DEVICE, keep_on_device=True)   # ref decode.py:69-73
     cfg = FeatCfg.from_constants()
+    if ACTIVATION is not None and ACTIVATION != cfg.activation:   # the file says which network it holds: it wins over constants.py
+        cfg.activation = ACTIVATION
     # the parameter count the header's network shape needs: a payload that holds another number is refused before
     # anything is sized by it (ref decode.py:114-120 slices the vector by state_dict shapes)
     need = ops.param_count(ops.make_net(cfg.feature_dim(int(base.shape[0]), D), bc, int(base.shape[0]), nl))
@@ -48,7 +51,7 @@ def test(bitstream, dirname, filename, nn_bytes, base_bytes, write=True):
 
 
 def main(argv=None, shard_tiles=None):
-    global K, D, bc, nl, DEVICE
+    global K, D, bc, nl, DEVICE, ACTIVATION
     p = argparse.ArgumentParser(description="LBDRN-RSIC")
     p.add_argument("--seed", type=int, default=19920517)
     p.add_argument("-i", "--bin_path", type=str, help="binstream path")
@@ -87,6 +90,9 @@ def main(argv=None, shard_tiles=None):
     with open(args.bin_path, "rb") as fin:
         bitstream = fin.read()
     n_hdr, split_ratio, width, height, K, bc, nl, D, nn_list, base_list = read_image_header(bitstream)
+    ACTIVATION = container.header_activation(bitstream)
+    if ACTIVATION is not None and ACTIVATION != FeatCfg.from_constants().activation:
+        logger.log.info(f"hidden activation {ACTIVATION} (from the header; constants.HIDDEN_ACTIVATION says otherwise)")
     bitstream = bitstream[n_hdr:]
     recon_path = f"{dirname}/{basename[:-4]}_recon.tif"
     if split_ratio > 1:

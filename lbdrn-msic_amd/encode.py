@@ -251,7 +251,7 @@ def main(argv=None, shard_tiles=None):
                 logger.replay(lines)
         header = container.pack_header(args.split_ratio, width, height, args.K, args.base_channel,
                                        args.num_layers, args.D, [len(rec[1]) for rec in tiles],
-                                       [len(rec[2]) for rec in tiles])
+                                       [len(rec[2]) for rec in tiles], activation=FeatCfg.from_constants().activation)
         with open(bitstream_path, "wb") as f:
             f.write(header)
             for _, nn, base, _ in tiles:

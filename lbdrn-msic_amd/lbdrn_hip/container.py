@@ -30,7 +30,16 @@ BASE_LBB2_MAGIC = b"LBB2"
 
 # ---------------------------------------------------------------- header
 
-def pack_header(split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_bytes_list):
+HEADER_FLAG_RELU = 0x01      # bit 0 of the extension byte: the hidden activation is torch.nn.ReLU (constants.HIDDEN_ACTIVATION)
+
+
+def pack_header(split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_bytes_list, activation="sine"):
+    """The reference's header (ref encode.py:37-64), byte for byte -- for the default network.  activation="relu" (the
+    reference's alternative, a source edit there: encode.py:75 / decode.py:108) appends ONE extension byte behind the
+    reference's fields and counts it in the length byte: the reference's reader strips `n_bytes_header` bytes whatever they are
+    (decode.py:26, 182), so such a file still parses there, and this package's decoder no longer depends on both sides
+    having made the same edit (a file encoded with relu and decoded under the default constants gave
+    garbage low bits without an error)."""
     tiles = split_ratio * split_ratio
     if len(nn_bytes_list) != tiles or len(base_bytes_list) != tiles:
         raise ValueError("one nn and one base size per tile expected")
@@ -41,7 +50,10 @@ def pack_header(split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_by
                         ("width", width, 65535), ("height", height, 65535), ("split_ratio", split_ratio, 255)):
         if not 0 <= v <= hi:
             raise OverflowError(f"{name}={v} does not fit its header field (max {hi})")
-    n = 8 + 7 * tiles
+    if activation not in ("sine", "relu"):
+        raise ValueError(f"hidden activation {activation!r}")
+    ext = bytes([HEADER_FLAG_RELU]) if activation == "relu" else b""
+    n = 8 + 7 * tiles + len(ext)
     if n > 255:
         raise OverflowError(f"header of {n} bytes does not fit its one-byte length field")
     out = struct.pack(">BBHHBB", n, split_ratio, width, height, (K << 4) | D, (log2bc << 4) | nl)
@@ -53,8 +65,21 @@ def pack_header(split_ratio, width, height, K, bc, nl, D, nn_bytes_list, base_by
         if not 0 <= b < 1 << 32:
             raise OverflowError(f"base payload of {b} bytes does not fit 4 bytes")
         out += struct.pack(">I", b)
+    out += ext
     assert len(out) == n
     return out
+
+
+def header_activation(buf):
+    """The hidden activation a header names: "relu" / "sine" from the extension byte, None where the header has none (every
+    reference-written file and every default-network file: the decoder then takes constants.HIDDEN_ACTIVATION, as before)."""
+    n, sr = buf[0], buf[1]
+    base = 8 + 7 * sr * sr
+    if n <= base:
+        return None
+    if n > base + 1 or buf[base] & ~HEADER_FLAG_RELU:
+        raise ValueError(f"header extension of {n - base} byte(s) / flags {buf[base]:#x}: written by a newer version of this package")
+    return "relu" if buf[base] & HEADER_FLAG_RELU else "sine"
 
 
 def unpack_header(buf):

@@ -3,6 +3,8 @@ at ref encode.py:75 and decode.py:108 -- through the C ABI (lbdrn_net.act = LBDR
 parameter of the fused kernels k_apply_mfma / k_train_stream / k_train_split at bc <= 128 / bc = 64, the generic LDS-tiled
 kernels elsewhere): bit-exact against the oracle where the result is integers or canonical float32, within the training
 tolerance against the reference's own model / loss / Adam (tests/golden/make_golden_relu.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -285,9 +287,17 @@ def test_a_whole_fit_and_the_clis_with_relu(dev, tmp_path, monkeypatch, bc):
     assert decode.main(["-i", str(sub / "t.bin")]) in (0, None)      # (without -org: the raster stays for the checks)
     rec = raster_io.read_raster(str(sub / "t_recon.tif"))
     assert np.array_equal(rec >> K, img >> K)
-    # the same stream under the default activation decodes to other low bits: the switch is not in the bitstream (as in
-    # the reference, where both sides edit the same source line)
+    # the same stream under the DEFAULT constants decodes to the same raster: since round 6 the file says which network it
+    # holds (one extension byte behind the reference's header fields, container.pack_header) -- in round 5 this gave other
+    # low bits without an error, as it does in the reference where both sides edit the same source line
+    from lbdrn_hip import container
+    raw = (sub / "t.bin").read_bytes()
+    assert container.header_activation(raw) == "relu" and raw[0] == 8 + 7 * 4 + 1
     monkeypatch.setattr(constants, "HIDDEN_ACTIVATION", "sine")
+    os.remove(str(sub / "decode.txt"))
     assert decode.main(["-i", str(sub / "t.bin")]) in (0, None)
     rec2 = raster_io.read_raster(str(sub / "t_recon.tif"))
-    assert np.array_equal(rec2 >> K, img >> K) and not np.array_equal(rec2, rec)
+    assert np.array_equal(rec2, rec)
+    # a header without the byte (every reference-written file, every default-network file) leaves the choice to constants.py
+    legacy = bytes([raw[0] - 1]) + raw[1:raw[0] - 1] + raw[raw[0]:]
+    assert container.header_activation(legacy) is None and container.unpack_header(legacy)[1:] == container.unpack_header(raw)[1:]

@@ -785,3 +785,40 @@ def test_lone_fit_schedule_guess_is_close_to_its_measurement(dev, bands):
     # ... and wherever the line was drawn, the fits are one fit
     for f in fits[1:]:
         assert torch.equal(f.best_params.view(torch.int32), fits[0].best_params.view(torch.int32))
+
+
+def test_epoch_calls_queued_back_to_back_equal_synchronised_ones(dev):
+    """What the shipped library shares with round 5's dropped overlap experiment -- whose variants all aborted when two epoch
+    calls were queued back to back -- is exactly that: calls queued behind one another on one stream, each
+    opening with its packing launches while the previous call's last reduce launch may still run (codec.fit_device queues two
+    per epoch: head and rest).  Twenty-four calls in a row, the lone-fit hint alternating (k_train_stream / k_train_split), no
+    host synchronisation in between, against the same calls with a synchronisation after each: identical bits; 8- and 4-band."""
+    rng = np.random.default_rng(23)
+    for C, H, W, bs in ((8, 70, 90, 512), (4, 61, 47, 300)):
+        img = synthetic_tile(9, C, H, W)
+        msb, _, mx = O.split_bits(img, 5)
+        cfg = FeatCfg()
+        F = cfg.feature_dim(C, 2)
+        geom = ops.FeatureGeometry(C, H, W, 5, 2, mx, cfg, dev)
+        net = ops.make_net(F, 64, C, 2)
+        p0 = _params(rng, F, 64, C, 2)
+        perms = [torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev) for _ in range(3)]
+        img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+        steps = (H * W + bs - 1) // bs
+        got = []
+        for sync in (True, False):
+            p = torch.from_numpy(p0.copy()).to(dev)
+            m, v = torch.zeros_like(p), torch.zeros_like(p)
+            losses = torch.zeros((24, steps), dtype=torch.float32, device=dev)
+            ws = ops.TrainWorkspace(geom, net, bs, dev).prepare(img_d, msb_d, MFMA)
+            torch.cuda.synchronize()
+            for k in range(24):
+                ops.train_epoch(geom, net, img_d, msb_d, perms[k % 3], bs, p, m, v, k * steps, 1e-3, losses[k], path=MFMA, ws=ws,
+                                alone=bool(k & 1))
+                if sync:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            got.append([t.cpu().numpy().view(np.int32) for t in (p, m, v, losses)])
+        for a, b in zip(*got):
+            assert np.array_equal(a, b), C
+        assert np.isfinite(got[0][3].view(np.float32)).all()

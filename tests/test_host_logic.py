@@ -96,6 +96,26 @@ def test_header_pack_unpack_vs_reference_bytes(golden):
                           [1] * t, [1] * t)
     with pytest.raises(OverflowError):
         c.pack_header(1, 8, 8, 5, 64, 2, 2, [1 << 24], [1])
+    # the hidden activation rides in ONE extension byte behind the reference's fields, counted by the length byte -- which is
+    # all the reference's reader goes by (ref decode.py:26, 182: bitstream[n_bytes_header:]); the default network's header is
+    # the reference's, byte for byte (above)
+    for i in range(4):
+        a = [int(v) for v in G[f"h{i}/args"]]
+        nn, bb = [int(v) for v in G[f"h{i}/nn"]], [int(v) for v in G[f"h{i}/base"]]
+        ref = G[f"h{i}/bytes"].tobytes()
+        assert c.header_activation(ref) is None
+        if ref[0] == 255:
+            with pytest.raises(OverflowError):
+                c.pack_header(a[0], a[1], a[2], a[3], a[4], a[5], a[6], nn, bb, activation="relu")
+            continue
+        raw = c.pack_header(a[0], a[1], a[2], a[3], a[4], a[5], a[6], nn, bb, activation="relu")
+        assert raw == bytes([ref[0] + 1]) + ref[1:] + b"\x01" and c.header_activation(raw) == "relu"
+        assert c.unpack_header(raw)[1:] == c.unpack_header(ref)[1:] and c.unpack_header(raw)[0] == len(raw)
+        with pytest.raises(ValueError):
+            c.header_activation(raw[:-1] + b"\x02")
+        assert c.header_activation(raw[:-1] + b"\x00") == "sine"
+    with pytest.raises(ValueError):
+        c.pack_header(1, 8, 8, 5, 64, 2, 2, [1], [1], activation="tanh")
 
 
 def test_model_init_and_rng_position_vs_reference(golden):

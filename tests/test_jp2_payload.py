@@ -79,6 +79,17 @@ def test_damaged_and_foreign_streams_are_refused(jp2):
     b = jp2.encode(x)
     with pytest.raises(jp2.Jp2Error):
         jp2.decode(b[:len(b) // 2])
+    # what OpenJPEG said reaches the caller whichever of the codec's threads met it: a per-call context, not the reporting
+    # thread's thread-local buffer (csrc/jp2_shim.c: err_ctx)
+    big = jp2.encode(np.random.default_rng(1).integers(0, 300, (4, 300, 300)).astype(np.uint16))
+    old = jp2.set_threads(8)
+    try:
+        for cut in (len(big) // 2, 200):
+            with pytest.raises(jp2.Jp2Error) as e:
+                jp2.decode(big[:cut])
+            assert "openjpeg: " in str(e.value) and not str(e.value).endswith(("decoding failed", "cannot read the header", ": "))
+    finally:
+        jp2.set_threads(old)
     with pytest.raises(jp2.Jp2Error):
         jp2.decode(b"not a jpeg 2000 stream at all")
     with pytest.raises(ValueError):

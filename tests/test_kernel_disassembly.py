@@ -88,3 +88,23 @@ def test_shipped_library_exports_the_c_abi_only_and_no_kernel_uses_scratch():
     for f in os.listdir(csrc):
         if f.endswith((".hip", ".inc", ".hpp", ".c")):
             assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+
+
+def test_nothing_of_the_dropped_overlap_experiment_ships():
+    """Round 5's "next training launch beside the reduce launch" experiment (scripts/experiments/reduce_beside_next_launch.patch)
+    ended in a SIGABRT from the runtime whose cause was never established.  None of its mechanisms is in the
+    library: no launch through hipExtLaunchKernelGGL / hipExtAnyOrderLaunch, no kernel that waits in a loop for another
+    launch's store (s_sleep / a polling atomic load), no release / acquire fence between launches, no sync words in the
+    training workspace.  A launch of this library depends on its predecessors through stream order only."""
+    csrc = os.path.join(ROOT, "lbdrn-msic_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".inc", ".hpp")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        for word in ("hip_ext.h", "hipExtLaunchKernelGGL", "hipExtAnyOrderLaunch", "s_sleep", "off_sync",
+                     "hipStreamWaitEvent", "hipEventRecord"):
+            assert word not in src, f"{f}: {word}"
+        # (fences of wavefront scope order a wave's own LDS traffic -- randperm.hip --; what the experiment had were fences of
+        #  agent scope between two launches)
+        for m in re.finditer(r"__builtin_amdgcn_fence\(([^)]*)\)", src):
+            assert '"agent"' not in m.group(1) and '"system"' not in m.group(1) and m.group(1).strip().endswith('"wavefront"'), f"{f}: {m.group(0)}"
