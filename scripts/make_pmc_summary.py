@@ -112,7 +112,7 @@ for cfg, kernels in KERNELS.items():
                 e["mfma_busy_frac_occupied_simds"] = e["mfma_busy_frac_whole_chip"]
             if key == "train":   # 128 workgroups of one fit (pair, and the 256 32-row workgroups of bc256: every CU), one compute
                                  # wave per SIMD: 512 (1024) of the chip's 1024 SIMDs
-                e["mfma_busy_frac_occupied_simds"] = round((1 if cfg in ("pair", "bc256") else 2) * e["mfma_busy_frac_whole_chip"], 4)
+                e["mfma_busy_frac_occupied_simds"] = round((1 if (cfg in ("pair", "bc256") or cfg.endswith("_pair")) else 2) * e["mfma_busy_frac_whole_chip"], 4)
         if conf:
             e.update(lds_bank_conflict_cycles_per_launch=conf[1], lds_active_cycles_per_launch=ldsact[1] if ldsact else None)
         if coexec:
@@ -124,7 +124,7 @@ for cfg, kernels in KERNELS.items():
         if e:
             cout[key] = e
     if cout:
-        cout["algorithmic_bytes_per_train_launch"] = 8192 * 16 * (2 if cfg == "pair" else 1)
+        cout["algorithmic_bytes_per_train_launch"] = 8192 * (8 if cfg.startswith("bands4") else 16) * (2 if (cfg == "pair" or cfg.endswith("_pair")) else 1)
         out["configs"][cfg] = cout
 for cfg, csv_name in list(TRACE.items()) + [("split", None), ("split_embed", None)]:
     t = trace_avg(csv_name, KERNELS.get(cfg, KERNELS["embed"])["train"]) if csv_name else None
