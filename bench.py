@@ -335,7 +335,7 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
         tr, ap = prof.get("train", {}), prof.get("apply_eval", {})
         pair = per_launch == 2 and (key == "bc64" or prof.get("_pair_counters"))
         out["traffic"] = tr.get("hbm_bytes_per_launch")
-        out["traffic_algorithmic_bytes"] = B * 16 * (2 if pair else 1)
+        out["traffic_algorithmic_bytes"] = B * 2 * net.C * (2 if pair else 1)   # one read of the uint16 source: 2 bytes a band
         out["traffic_note"] = ("counter values are per launch of a pair of fits (scripts/prof_pair.py)" if pair
                                else "counter values are per launch of ONE fit's minibatch (scripts/prof_fit.py runs one fit at a time)")
         out["traffic_kernel"] = tr.get("kernel")

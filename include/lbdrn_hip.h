@@ -70,8 +70,11 @@ typedef struct lbdrn_net {
     int32_t F, bc, C, nl;
     int32_t act;          /* hidden activation (LBDRNmodel.py:37,75): LBDRN_ACT_SINE = the default Sine(w0 = 30);
                            * LBDRN_ACT_RELU = LBDRNModel(activation=torch.nn.ReLU()), the alternative the reference names
-                           * (encode.py:75, decode.py:108) -- LDS-tiled generic kernels only: LBDRN_PATH_MFMA answers
-                           * LBDRN_E_UNSUPPORTED, LBDRN_PATH_AUTO takes the generic path.  The head is always Sigmoid. */
+                           * (encode.py:75, decode.py:108).  Since round 6 the fused kernels take it as a template argument
+                           * wherever they take the Sine network at bc <= 128 (apply: bc 32 / 64 / 128; training: bc = 64, one
+                           * or two hidden layers); the bc >= 128 training / bc = 256 apply kernels and the nl = 3 training
+                           * kernel are the Sine network's: there LBDRN_PATH_MFMA answers LBDRN_E_UNSUPPORTED and
+                           * LBDRN_PATH_AUTO takes the LDS-tiled generic kernels.  The head is always Sigmoid. */
 } lbdrn_net;
 enum { LBDRN_ACT_SINE = 0, LBDRN_ACT_RELU = 1 };
 
@@ -143,7 +146,10 @@ int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *im
  * of pixel indices: gather features and labels, forward, MSE loss, backward, Adam update of
  * params/exp_avg/exp_avg_sq in place.  adam_step0 = number of Adam steps already taken;
  * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
- * short (no drop_last, encode.py:69). */
+ * short (no drop_last, encode.py:69) -- down to ONE row; no byte of perm beyond its n elements is read.
+ * batch_size: any value >= 1 (the reference takes any -bs).  The fused bc = 64 step addresses one step's gradient slabs
+ * with 32-bit offsets: where they would pass 2 GiB (about a million rows per minibatch at the headline shape)
+ * LBDRN_PATH_MFMA answers LBDRN_E_UNSUPPORTED and LBDRN_PATH_AUTO runs the generic step (same tolerance contract). */
 size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
 /* path of lbdrn_train_epoch may carry LBDRN_TRAIN_ALONE (path | LBDRN_TRAIN_ALONE): a HINT that nothing else of weight
  * runs on the device beside this fit's steps (the reference's own situation: one image after another, run.sh:29-42).

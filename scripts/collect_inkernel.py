@@ -32,6 +32,9 @@ STAMPS = {
     # the every-CU launch of a fit that has the device to itself (k_train_split: 256 workgroups of 32 rows), real epochs
     "split": ("one fit per launch on every CU (LBDRN_TRAIN_ALONE), alone on the device", ["scripts/lone_step_probe.py", "3", "--only", "split", "--modes", "0"]),
     "split_embed": ("USE_COORDINATES + EMBEDDING, every-CU launch, alone", ["scripts/lone_step_probe.py", "3", "--embed", "--only", "split", "--modes", "0"]),
+    # the reference's 4-band shape (F = 100): the pair launch of fits in flight and the every-CU launch of a lone fit
+    "bands4_pair": ("4 bands, two fits per launch (2 x 128 workgroups), alone on the device", ["scripts/stamp_probe_group.py", "2", "bands4"]),
+    "bands4": ("4 bands, one fit per launch on every CU (LBDRN_TRAIN_ALONE), alone on the device", ["scripts/lone_step_probe.py", "3", "--bands4", "--only", "split", "--modes", "0"]),
 }
 TIMELINE = {
     "bc64": ("one chain of single-fit launches, alone on the device", ["scripts/stamp_probe_inflight.py", "1", "3", "8", "2", "1"]),
@@ -41,6 +44,11 @@ TIMELINE = {
                         ["scripts/stamp_probe_inflight.py", "4", "3", "8", "2", "2"]),
     "split": ("one chain of every-CU launches (k_train_split) and their reduce launches over slab pairs, alone on the device",
               ["scripts/lone_step_probe.py", "3", "--only", "split", "--modes", "0"]),
+    "bands4_pair": ("4 bands: one chain of pair launches, alone on the device", ["scripts/stamp_probe_inflight.py", "2", "3", "4", "2", "2"]),
+    "bands4_pair_two_chains": ("4 bands: two chains of pair launches in flight (the bands4 leg of bench.py)",
+                               ["scripts/stamp_probe_inflight.py", "4", "3", "4", "2", "2"]),
+    "bands4": ("4 bands: one chain of every-CU launches (k_train_split<24,6>), alone on the device",
+               ["scripts/lone_step_probe.py", "3", "--bands4", "--only", "split", "--modes", "0"]),
 }
 
 

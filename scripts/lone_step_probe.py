@@ -2,7 +2,7 @@
 k_train_stream (128 workgroups of 64 rows; alone=False) and k_train_split (256 workgroups of 32 rows; alone=True).
 HIP events around whole 512-step epochs on the full 8 x 2048^2 tile, lbdrn_train_profile_mode as in bench.py:
 mode 0 = the real epoch, 3 = training launches alone (cold rows), 2 = training launch doubled, 1 = reduce doubled.
-usage: lone_step_probe.py [repeats=3] [--embed] [-bc N] [--only stream|split] [--modes 0,3,2,1]
+usage: lone_step_probe.py [repeats=3] [--embed | --bands4] [-bc N] [--only stream|split] [--modes 0,3,2,1]
 (--only / --modes: what scripts/collect_inkernel.py runs under the stamped and timeline builds -- one kernel, real epochs only)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,7 @@ only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 modes = tuple(int(x) for x in sys.argv[sys.argv.index("--modes") + 1].split(",")) if "--modes" in sys.argv else (0, 3, 2, 1)
 kinds = [k for k in (False, True) if only is None or (only == "split") == k]
 dev = torch.device("cuda:0")
-C, H, W, K, D, nl, bs = 8, 2048, 2048, 5, 2, 2, 8192
+C, H, W, K, D, nl, bs = (4 if "--bands4" in sys.argv else 8), 2048, 2048, 5, 2, 2, 8192
 cfg = FeatCfg(True, True, 1.4, 12, True, True) if embed else FeatCfg(False, False, 1.4, 12, True, True)
 img = synthetic_tile(0, C, H, W)
 img_d = ops.to_device_u16(img, dev)

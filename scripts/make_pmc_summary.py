@@ -157,7 +157,7 @@ for cfg, csv_name in list(TRACE.items()) + [("split", None), ("split_embed", Non
                                             "first_start_to_last_end_us", "source") if k in j}
     if not cout:
         del out["configs"][cfg]
-for extra in ("timeline_bc64_two_chains.json", "timeline_pair_two_chains.json"):   # the timed region itself: two chains in flight
+for extra in ("timeline_bc64_two_chains.json", "timeline_pair_two_chains.json", "timeline_bands4_pair_two_chains.json"):   # the timed region itself: two chains in flight
     j = load_json(extra)
     if j and j.get("per_step_us"):
         out.setdefault("timeline_in_flight", {})[extra[len("timeline_"):-len(".json")]] = {

@@ -10,9 +10,10 @@ from lbdrn_hip.synth import synthetic_tile
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 from lbdrn_hip.features import FeatCfg
 embed = len(sys.argv) > 2 and sys.argv[2] == "embed"
+bands = 4 if len(sys.argv) > 2 and sys.argv[2] == "bands4" else 8
 cfg = FeatCfg(use_coordinates=embed, embedding=embed)
 dev = torch.device("cuda:0")
-imgs = [ops.to_device_u16(synthetic_tile(i, 8, 2048, 2048), dev) for i in range(n)]
+imgs = [ops.to_device_u16(synthetic_tile(i, bands, 2048, 2048), dev) for i in range(n)]
 for _ in range(4):   # (the stamped build prints one line per epoch call; collect_inkernel.py drops the first)
     if n == 1:
         torch.manual_seed(19920517); codec.fit_device(imgs[0], 5, 2, 64, 2, 1e-3, 8192, 1, cfg=cfg)

@@ -39,7 +39,8 @@ def _random_case(rng, train):
     rel = bool(rng.integers(0, 2))
     bc = 64 if train else int(rng.choice([32, 64, 128]))
     nl = int(rng.integers(1, 4))
-    cfg = FeatCfg(coords, embed, 1.4, 12, colors, rel)
+    act = "relu" if rng.integers(0, 3) == 0 else "sine"      # (round 6: the fused kernels take either hidden activation)
+    cfg = FeatCfg(coords, embed, 1.4, 12, colors, rel, act)
     hi = int(rng.choice([255, 4000, 10000, 65535]))
     img = rng.integers(0, hi + 1, (C, H, W)).astype(np.uint16)
     return C, H, W, K, D, bc, nl, cfg, img
@@ -48,7 +49,7 @@ def _random_case(rng, train):
 def test_apply_fuzz_mfma_equals_generic_and_oracle(dev):
     rng = np.random.default_rng(20240101)
     checked_oracle = 0
-    ran = 0
+    ran = relus = 0
     for it in range(24 * SOAK):
         C, H, W, K, D, bc, nl, cfg, img = _random_case(rng, train=False)
         F = cfg.feature_dim(C, D)
@@ -59,8 +60,8 @@ def test_apply_fuzz_mfma_equals_generic_and_oracle(dev):
         if mx == 0:
             continue
         geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
-        net = ops.make_net(F, bc, C, nl)
-        p = torch.from_numpy(_params(rng, F, bc, C, nl, 2.5)).to(dev)
+        net = ops.make_net(F, bc, C, nl, cfg.act)
+        p = torch.from_numpy(_params(rng, F, bc, C, nl, 2.5 * (30.0 if cfg.act else 1.0))).to(dev)   # (no w0 = 30 in front of a ReLU)
         msb_d, img_d = ops.to_device_u16(msb, dev), ops.to_device_u16(img, dev)
         try:
             a, ya = ops.decode_fused(geom, net, msb_d, p, want_y=True, path=MFMA)
@@ -74,12 +75,14 @@ def test_apply_fuzz_mfma_equals_generic_and_oracle(dev):
         s2 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item())
         assert abs(s1 - s2) <= 1e-11 * max(s2, 1e-30), tag
         ran += 1
-        if H * W <= 2500 and checked_oracle < 8:
+        relus += cfg.act
+        if H * W <= 2500 and checked_oracle < 8 + 4 * cfg.act:
             ocfg = O.FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative)
-            ro = O.decode(msb, K, D, ocfg, p.cpu().numpy(), bc, nl, mx)
+            with O.hidden_activation(cfg.activation):
+                ro = O.decode(msb, K, D, ocfg, p.cpu().numpy(), bc, nl, mx)
             assert np.array_equal(ops.from_device_u16(a), ro), tag
             checked_oracle += 1
-    assert ran >= 10 and checked_oracle >= 3, (ran, checked_oracle)
+    assert ran >= 10 and checked_oracle >= 3 and relus >= 2, (ran, checked_oracle, relus)
 
 
 def test_apply_fuzz_streaming_kernel_equals_generic_and_oracle(dev):
@@ -128,8 +131,8 @@ def test_train_fuzz_mfma_matches_generic(dev):
         if mx == 0 or F > 256:
             continue
         geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
-        net = ops.make_net(F, 64, C, nl)
-        p0 = _params(rng, F, 64, C, nl, 1.0)
+        net = ops.make_net(F, 64, C, nl, cfg.act)
+        p0 = _params(rng, F, 64, C, nl, 10.0 if cfg.act else 1.0)
         bs = int(rng.choice([64, 100, 257, 1000]))
         img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
         order = rng.permutation(H * W).astype(np.int64)
@@ -169,8 +172,8 @@ def test_train_fuzz_mfma_matches_generic(dev):
 def test_two_training_kernels_one_set_of_bits_fuzz(dev):
     """k_train_stream (64-row workgroups, half the chip: the step with company) and k_train_split (32-row workgroups, units
     halved between two waves, every CU: the step of a fit alone, LBDRN_TRAIN_ALONE) share one summation tree
-    (csrc/train_split.inc): on random images of the two shapes that have both -- F = 200 and the embedding's F = 250 at
-    bc = 64, two hidden layers --, random K, batch sizes that leave ragged groups, one-row tails and minibatches shorter than a
+    (csrc/train_split.inc): on random images of the shapes that have both -- F = 200, the embedding's F = 250 and (round 6) the
+    reference's 4-band F = 100 at bc = 64, two hidden layers; either hidden activation --, random K, batch sizes that leave ragged groups, one-row tails and minibatches shorter than a
     workgroup, two epochs of each leave the same parameters, Adam moments and losses bit for bit, and they train."""
     rng = np.random.default_rng(20260105)
     MFMA = ops._lib.PATH_MFMA
@@ -179,6 +182,10 @@ def test_two_training_kernels_one_set_of_bits_fuzz(dev):
     for it in range(12 * SOAK):
         cfg = shapes[it % 2]
         C, D, bc, nl = (8, 2, 64, 2) if it % 4 < 2 else (4, 3, 64, 2)   # (4 bands x 7 x 7: the same 192 / 242 features, half the channels)
+        if it % 6 == 4:                                # the 4-band shape of the reference's own images: 96 features multiplied
+            cfg, C, D = shapes[0], 4, 2
+        act = "relu" if it % 3 == 2 else "sine"
+        cfg = FeatCfg(cfg.use_coordinates, cfg.embedding, 1.4, 12, cfg.use_colors, cfg.relative, act)
         H, W, K = int(rng.integers(5, 40)), int(rng.integers(5, 60)), int(rng.integers(1, 8))
         bs = int(rng.choice([33, 64, 65, 100, 257, 1000, H * W - 1, H * W + 7]))
         bs = max(bs, 2)
@@ -191,9 +198,9 @@ def test_two_training_kernels_one_set_of_bits_fuzz(dev):
             continue
         F = cfg.feature_dim(C, D)
         geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
-        net = ops.make_net(F, bc, C, nl)
-        assert ops.train_step_features(geom, net) in (192, 242)      # (the two shapes that have both kernels)
-        p0 = _params(rng, F, bc, C, nl, 1.0)
+        net = ops.make_net(F, bc, C, nl, cfg.act)
+        assert ops.train_step_features(geom, net) in (192, 242, 96)      # (the shapes that have both kernels)
+        p0 = _params(rng, F, bc, C, nl, 10.0 if cfg.act else 1.0)
         perm = torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev)
         img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
         steps = (H * W + bs - 1) // bs
