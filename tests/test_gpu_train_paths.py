@@ -822,3 +822,63 @@ def test_epoch_calls_queued_back_to_back_equal_synchronised_ones(dev):
         for a, b in zip(*got):
             assert np.array_equal(a, b), C
         assert np.isfinite(got[0][3].view(np.float32)).all()
+
+
+def test_full_size_properties_four_bands(dev):
+    """The reference's majority shape at full size (4 x 2048^2, K5 D2 bc64 nl2, F = 100; run.sh:14-28): the generic and the
+    fused apply kernels agree bit for bit on the 16.8 M decoded sub-pixels and to 1e-12 on the whole-image SSE, a background
+    pass gives the same double, the high bits survive, the error is bounded by the dropped bits; then the fit itself, two
+    epochs: two runs identical bit for bit, the MSE it selected on equals the MSE recomputed from the decode kernel's outputs
+    (independent kernels), the reconstruction beats "predict mid-range"; and a PAIR of such fits in flight (the launch sequence
+    of the bench line's bands4 leg: k_train_stream<24,2,3,6>) equals the same fits alone (mostly k_train_split<24,6>)."""
+    C, H, W, K, D = 4, 2048, 2048, 5, 2
+    tiles_np = [synthetic_tile(21 + k, C, H, W) for k in range(2)]
+    img = tiles_np[0]
+    img_d = ops.to_device_u16(img, dev)
+    msb_d, mx = ops.split_bits(img_d, K)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(100, 64, C, 2)
+    p = torch.from_numpy(_params(np.random.default_rng(4), 100, 64, C, 2) * 2.0).to(dev)
+    a = ops.decode_fused(geom, net, msb_d, p, path=MFMA)
+    assert torch.equal(a, ops.decode_fused(geom, net, msb_d, p, path=GEN))
+    rec = ops.from_device_u16(a)
+    assert np.array_equal(rec >> K, img >> K) and np.abs(rec.astype(np.int32) - img.astype(np.int32)).max() <= 31
+    s1 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA).item())
+    s2 = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=GEN).item())
+    assert abs(s1 - s2) <= 1e-12 * s2
+    assert float(ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA, background=True).item()) == s1
+    fast = float(ops.eval_sse(geom, net, img_d, msb_d, p, path=MFMA, fast=True).item())
+    assert abs(fast - s1) <= 1e-6 * s1
+    # the fit
+    fits = []
+    for _ in range(2):
+        torch.manual_seed(19920517)
+        fits.append(codec.fit_device(img_d, K, D, 64, 2, 1e-3, 8192, 2, keep_losses=True))
+    f0, f1 = fits
+    assert torch.equal(f0.best_params.view(torch.int32), f1.best_params.view(torch.int32))
+    assert torch.equal(f0.losses, f1.losses) and torch.equal(f0.mse_log, f1.mse_log)
+    assert ops.train_step_features(f0.geom, f0.net) == 96
+    losses = f0.losses.cpu().numpy()
+    assert np.isfinite(losses).all() and losses[1].mean() <= losses[0].mean()
+    mse_log = f0.mse_log.cpu().numpy()
+    best = int(np.argmin(mse_log[:, 0]))
+    out, y = ops.decode_fused(f0.geom, f0.net, f0.msb, f0.best_params, want_y=True)
+    lab = ops.labels(img_d, K)
+    mse_indep = float(((y.double() - lab.double()) ** 2).mean().item())
+    assert abs(mse_indep - float(mse_log[best, 0])) <= 2e-6 * mse_indep
+    rec = ops.from_device_u16(out)
+    assert np.array_equal(rec >> K, img >> K)
+    err = float(np.mean((rec.astype(np.float32) - img.astype(np.float32)) ** 2))
+    base = float(np.mean(((((img >> K) << K) + 16).astype(np.float32) - img.astype(np.float32)) ** 2))
+    assert err < base
+    # a pair in flight against the same fits alone
+    tiles = [img_d, ops.to_device_u16(tiles_np[1], dev)]
+    assert ops.train_group_size(C, H, W, K, D, FeatCfg(), 64, 2) >= 2
+    together = codec.fit_many(tiles, K, D, 64, 2, 1e-3, 8192, 2, cfg=FeatCfg(), seed=19920517, in_flight=4)
+    torch.cuda.synchronize()
+    for k, t in enumerate(tiles):
+        alone = codec.fit_many([t], K, D, 64, 2, 1e-3, 8192, 2, cfg=FeatCfg(), seed=19920517, in_flight=1)[0]
+        assert torch.equal(alone.best_params.view(torch.int32), together[k].best_params.view(torch.int32)), k
+        assert torch.equal(alone.mse_log, together[k].mse_log), k
+    assert torch.equal(together[0].best_params.view(torch.int32), f0.best_params.view(torch.int32))
+    assert not torch.equal(together[0].best_params, together[1].best_params)
