@@ -148,7 +148,7 @@ int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *im
  * losses (optional) receives one float32 minibatch loss per step.  The last minibatch may be
  * short (no drop_last, encode.py:69) -- down to ONE row; no byte of perm beyond its n elements is read.
  * batch_size: any value >= 1 (the reference takes any -bs).  The fused bc = 64 step addresses one step's gradient slabs
- * with 32-bit offsets: where they would pass 2 GiB (about a million rows per minibatch at the headline shape)
+ * with 32-bit offsets: where they would pass 2 GiB (about 0.9 million rows per minibatch at the headline shape)
  * LBDRN_PATH_MFMA answers LBDRN_E_UNSUPPORTED and LBDRN_PATH_AUTO runs the generic step (same tolerance contract). */
 size_t lbdrn_train_workspace(const lbdrn_geom *g, const lbdrn_net *net, int32_t batch_size);
 /* path of lbdrn_train_epoch may carry LBDRN_TRAIN_ALONE (path | LBDRN_TRAIN_ALONE): a HINT that nothing else of weight

@@ -273,7 +273,7 @@ static TrainWsLayout train_ws_layout(const lbdrn_geom& g, const lbdrn_net& net, 
 }
 
 // One step's set of slabs is read through ONE buffer resource with 32-bit byte offsets (k_reduce_adam): it must stay below
-// 2 GiB -- ~1 M rows per minibatch at the headline shape (a slab is 73 KB per 32 rows).  Larger minibatches take the
+// 2 GiB -- ~0.92 M rows per minibatch at the headline shape (a slab is 73 KB per 32 rows).  Larger minibatches take the
 // generic step (LBDRN_PATH_AUTO) or are refused (LBDRN_PATH_MFMA): ADVICE round 5.
 static bool slabs_addressable(const TrainPlan& p, int bs)
 {

@@ -882,3 +882,33 @@ def test_full_size_properties_four_bands(dev):
         assert torch.equal(alone.mse_log, together[k].mse_log), k
     assert torch.equal(together[0].best_params.view(torch.int32), f0.best_params.view(torch.int32))
     assert not torch.equal(together[0].best_params, together[1].best_params)
+
+
+def test_minibatches_whose_slabs_pass_2_gib_take_the_generic_step(dev):
+    """The reference takes any -bs.  The fused bc = 64 step reads one step's gradient slabs through a buffer resource with 32-bit
+    offsets (k_reduce_adam): a minibatch size whose slabs would pass 2 GiB (here 2.1 M rows: 65,625 slabs of 73 KB) is refused by
+    LBDRN_PATH_MFMA with LBDRN_E_UNSUPPORTED instead of wrapping silently, and LBDRN_PATH_AUTO runs it on the
+    generic kernels -- the same numbers as the generic path asked for by name."""
+    C, H, W, K, D, bs = 8, 40, 52, 5, 2, 2_100_000
+    img = synthetic_tile(5, C, H, W)
+    msb, _, mx = O.split_bits(img, K)
+    geom = ops.FeatureGeometry(C, H, W, K, D, mx, FeatCfg(), dev)
+    net = ops.make_net(200, 64, C, 2)
+    img_d, msb_d = ops.to_device_u16(img, dev), ops.to_device_u16(msb, dev)
+    with pytest.raises(ops._lib.LbdrnError) as e:
+        ops.TrainWorkspace(geom, net, bs, dev).prepare(img_d, msb_d, MFMA)
+    assert e.value.code == ops._lib.E_UNSUPPORTED
+    ops.TrainWorkspace(geom, net, 900_000, dev).prepare(img_d, msb_d, MFMA)        # (28,125 slabs = 2.10 GB: addressable)
+    rng = np.random.default_rng(3)
+    p0 = _params(rng, 200, 64, C, 2)
+    perm = torch.from_numpy(rng.permutation(H * W).astype(np.int64)).to(dev)
+    got = []
+    for path in (ops._lib.PATH_AUTO, GEN):
+        p = torch.from_numpy(p0.copy()).to(dev)
+        m, v = torch.zeros_like(p), torch.zeros_like(p)
+        losses = torch.zeros(1, dtype=torch.float32, device=dev)
+        ops.train_epoch(geom, net, img_d, msb_d, perm, bs, p, m, v, 0, 1e-3, losses, path=path)
+        got.append([t.cpu().numpy().view(np.int32) for t in (p, m, v, losses)])
+    for a, b in zip(*got):
+        assert np.array_equal(a, b)
+    assert np.isfinite(got[0][3].view(np.float32)).all()
