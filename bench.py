@@ -212,8 +212,9 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
     ws = ops.ApplyWorkspace(geom, net, img_d.device)
     p = fit.best_params
     fast = codec.fast_evaluation()    # the arithmetic the fit's own evaluation passes ran in
-    ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast)
-    t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast), stream, 3)
+    x16_on = fast and codec.exact16_evaluation()     # (only the opt-in leg: LBDRN_EVAL_X16=1)
+    ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast, x16=x16_on)
+    t_eval = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=fast, x16=x16_on), stream, 3)
     nsteps = (N + a.bs - 1) // a.bs
     peak = 157.3  # TFLOP/s, f32 MFMA == f32 vector peak (MI355X_MICROARCH.md)
     B = min(a.bs, N)
@@ -319,6 +320,12 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
         t_k = t_step
         out.update({"kernel": "generic train step (all launches of one minibatch)", "kernel_us": round(t_k * 1e3, 2)})
     ach = per_launch * step * B / (t_k * 1e-3) / 1e12
+    # the same pass with layer 0's colour features on the f16 matrix pipe, operands exact (LBDRN_EVAL_X16: OPT-IN, never part of
+    # `value`) -- what it would buy, measured
+    t_eval_x16 = None
+    if fast and path != ops._lib.PATH_GENERIC:
+        ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=True, x16=True)
+        t_eval_x16 = event_time_ms(lambda: ops.eval_sse(geom, net, img_d, fit.msb, p, path, ws, fast=True, x16=True), stream, 3)
     out.update({"achieved": round(ach, 3), "frac": round(ach / peak, 4), "frac_live": round(ach / peak, 4),
                 "train_step_pair_us": round(t_step * 1e3, 2),
                 "train_step_pair_tflops": round(per_launch * step * B / (t_step * 1e-3) / 1e12, 3),
@@ -326,7 +333,8 @@ def roofline_probe(codec, ops, fit, img_d, a, path, per_launch=None, with_single
                 "apply_frac": round(fwd * N / (t_eval * 1e-3) / 1e12 / peak, 4),
                 "apply_hbm_algorithmic_GBps": round(16.0 * N / (t_eval * 1e-3) / 1e9, 1),
                 "apply_pass": "the per-epoch evaluation pass as the fit runs it: " +
-                              ("LBDRN_EVAL_FAST (tolerance arithmetic)" if fast else "canonical arithmetic")})
+                              ("LBDRN_EVAL_FAST (tolerance arithmetic)" + (" + LBDRN_EVAL_X16 (opt-in)" if x16_on else "") if fast else "canonical arithmetic"),
+                "apply_pass_x16_ms_opt_in": round(t_eval_x16, 3) if t_eval_x16 is not None else None})
     if fused:
         # the kernel holds half of the chip (two fits' steps run side by side): the same rate against the peak of
         # the CUs it occupies
@@ -475,7 +483,7 @@ def lone_tile(codec, ops, tile, a, path, laps_n=3):
     return {"ms": ms, "encode_ms": enc, "decode_ms": dec, "fit": lone, "rec": rec}
 
 
-def side_leg(codec, ops, tiles, a, path, label, with_single=False, **over):
+def side_leg(codec, ops, tiles, a, path, label, with_single=False, env=None, **over):
     """A short leg of another BASELINE.json configuration inside the same call: warm-up tiles twice per in-flight stream,
     ONE timed region of `steps` tiles with `in_flight` progressing together, one tile alone (median of 3), the training
     launch's own duration (roofline_probe without the single-fit detour).  Same tiles, same method, same clock as the
@@ -483,6 +491,19 @@ def side_leg(codec, ops, tiles, a, path, label, with_single=False, **over):
     b = argparse.Namespace(**vars(a))
     for k, v in over.items():
         setattr(b, k, v)
+    saved = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        return _side_leg(codec, ops, tiles, b, path, label, with_single)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _side_leg(codec, ops, tiles, b, path, label, with_single):
     t_leg = time.perf_counter()
     take = [tiles[k % len(tiles)] for k in range(b.warmup + b.steps)]     # (inputs are read-only: a tile may serve twice)
     for _ in range(2):
@@ -505,7 +526,7 @@ def side_leg(codec, ops, tiles, a, path, label, with_single=False, **over):
     keep = ("kernel", "fits_per_launch", "kernel_us", "forward_backward_us", "weight_gradient_us", "marginal_us", "reduce_adam_us",
             "unaccounted_us", "train_step_pair_us", "features_multiplied",
             "flop_per_launch", "achieved", "frac", "frac_live", "frac_rocprof", "rocprof_kernel_us", "rocprof_source",
-            "rocprof_kernel_us_timed_region", "frac_timed_region", "rocprof_timed_region_source", "single_fit_launch",
+            "rocprof_kernel_us_timed_region", "frac_timed_region", "rocprof_timed_region_source", "single_fit_launch", "apply_pass_x16_ms_opt_in",
             "frac_of_occupied_cus", "apply_pass_ms", "apply_frac", "traffic", "mfma_busy_frac", "mfma_busy_frac_occupied_simds")
     out = {"workload": label, "steps": b.steps, "warmup": b.warmup, "tiles_in_flight": min(b.in_flight, b.steps),
            "tiles_per_launch": tiles_per_launch(b, ops, path), "repeats": 1,
@@ -771,6 +792,12 @@ def main():
                                   label="BASELINE.json configs[2]: the same tile, bc = 256 (k_train_half + k_dw_wide / k_apply_wide)"),
                 "embed": side_leg(codec, ops, tiles, a, path, coords_embedding=True, in_flight=4, steps=8, warmup=4,
                                   label="BASELINE.json configs[4]: USE_COORDINATES + EMBEDDING (F = 250)"),
+                # NOT the headline's arithmetic: the same tiles with the OPT-IN evaluation pass (LBDRN_EVAL_X16=1: layer 0's colour
+                # features on the f16 matrix pipe, integer differences x W_0 in three fp16 pieces, every product exact, float32
+                # sums; the training step and the decode pass as in the headline).  What DESIGN.md 10 prices, measured.
+                "x16_opt_in": side_leg(codec, ops, tiles, a, path, in_flight=4, steps=8, warmup=4, env={"LBDRN_EVAL_X16": "1"},
+                                       label="configs[1] with LBDRN_EVAL_X16=1 (opt-in; off in the headline): the per-epoch evaluation "
+                                             "passes take layer 0 through the f16 matrix pipe with exact operands"),
             }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a)

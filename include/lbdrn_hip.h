@@ -137,6 +137,15 @@ int lbdrn_decode_fused(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t
  * instead of two): msb must be exactly that plane -- as lbdrn_split_bits leaves it -- or NULL.  A caller whose MSB plane is
  * something else (a decoded or modified base) must leave the flag out. */
 #define LBDRN_EVAL_FAST 0x400
+/* With LBDRN_EVAL_FAST, path may also carry LBDRN_EVAL_X16 (round 6; OPT-IN: no caller of this package sets it by default): the
+ * colour features of layer 0 run on the f16 matrix pipe with EXACT operands.  A relative colour feature is
+ * (msb_nbr - msb_ctr) / max -- its numerator an integer of at most 11 bits, exactly an fp16 -- and a float32 weight is exactly
+ * the sum of three fp16 pieces once a power of two has brought it into range; v_mfma_f32_32x32x16_f16 multiplies them exactly
+ * and sums in float32, so the pre-activations are those of the float32 MFMA with FEWER roundings (nothing of a weight or of a
+ * feature is dropped), at 3/16 of its matrix-pipe cycles.  A hint: it takes effect where the shape and the image qualify
+ * (relative colours, no positional features, bc <= 64, D in 1..3, an even band count, g->msb_max <= 2047: any 16-bit image at
+ * K >= 5) and is ignored elsewhere.  *sse within 1e-6 relative of the flagless call like LBDRN_EVAL_FAST (measured: DESIGN.md 10). */
+#define LBDRN_EVAL_X16 0x1000
 int lbdrn_eval_sse(const lbdrn_geom *g, const lbdrn_net *net, const uint16_t *img,
                    const uint16_t *msb, const float *params, double *sse, void *workspace,
                    size_t workspace_bytes, int32_t path, void *stream);

@@ -27,6 +27,8 @@
 namespace lbdrn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef LBDRN_APPLY_CHUNK
 #define LBDRN_APPLY_CHUNK 20   // layer-0 steps whose B operands are made in one go, a multiple of 4 (0: four at a time, round
@@ -54,6 +56,10 @@ struct ApplyPlan {
                      // step (c, r) multiplies window position r of channel c in lane half 0 and of channel c + C/2 in lane
                      // half 1; with RELATIVE the window centre -- an exact zero -- is not a step
     int RS;          // pair: steps per channel pair = (2D+1)^2, minus the centre with RELATIVE
+    int x16;         // 1 (opt-in, LBDRN_EVAL_X16): the colour features of layer 0 on the f16 matrix pipe with EXACT operands
+                     // (layer0_pair_x16): integer window differences x W_0 in three fp16 pieces, f32 accumulation
+    int M16;         // x16: MFMAs per channel pair and weight piece = RS / 8
+    int off_scale;   // x16: one float, 2^-s / msb_max (what turns the scaled integer accumulator into the pre-activation)
     // float offsets inside the packed buffer == inside LDS
     int off_w0, off_wh, off_wl, off_bh, off_bl, pack_floats;
     // further LDS regions (float offsets)
@@ -61,7 +67,9 @@ struct ApplyPlan {
     int tiles_x, tiles_y;
 };
 
-static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, bool fast = false)
+constexpr int X16_PIECES = 3;   // fp16 pieces of a float32 weight: 3 x 11 bits hold all 24 of its mantissa
+
+static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, bool fast = false, bool x16 = false)
 {
     // hidden activation: Sine(30) (LBDRNmodel.py:37) or nn.ReLU (the alternative of encode.py:75 / decode.py:108): a template
     // parameter of k_apply_mfma
@@ -86,13 +94,18 @@ static bool make_plan(const lbdrn_geom& g, const lbdrn_net& net, ApplyPlan* p, b
     // (NT = 4, bc = 128: the pair's 24 operands on top of 128 accumulator / activation registers would spill at two waves per SIMD)
     q.RS = side * side - ((g.relative && g.D > 0) ? 1 : 0);
     if (q.pair) q.S0 = g.P + (g.C / 2) * q.RS;
+    // the exact-operand f16 layer 0: relative colours only (the differences of two MSB values are integers; (2D+1)^2 - 1 is a
+    // multiple of 8), no positional features, MSB values that fp16 holds exactly (<= 2047: any 16-bit image at K >= 5)
+    q.x16 = x16 && q.pair && g.relative && g.P == 0 && g.msb_max >= 1 && g.msb_max <= 2047 && (q.RS % 8) == 0;
+    q.M16 = q.RS / 8;
     const int half = net.bc / 2;
     int o = 0;
-    q.off_w0 = o; o += q.S0 * 64 * q.NT;
+    q.off_w0 = o; o += q.x16 ? (g.C / 2) * q.M16 * X16_PIECES * 64 * q.NT * 4 : q.S0 * 64 * q.NT;
     q.off_wh = o; o += (net.nl - 1) * half * 64 * q.NT;
     q.off_wl = o; o += half * 64;
     q.off_bh = o; o += net.nl * q.NT * 32;
     q.off_bl = o; o += 32;
+    q.off_scale = o; o += 4;
     q.pack_floats = o;
     q.off_ktab = o; o += 2 * 2 * (q.S0 - g.P) + 2;
     q.SW = TILE_W + 2 * g.D;
@@ -127,23 +140,87 @@ bool mfma_apply_supported(const lbdrn_geom& g, const lbdrn_net& net)
 
 constexpr int MFMA_PARTIALS = 1024;
 
+// the packed weights of the largest of a shape's plans | the SSE partials | one float: max |W_0| (x16)
+static size_t apply_pack_bytes(const lbdrn_geom& g, const lbdrn_net& net)
+{
+    ApplyPlan p, q;
+    make_plan(g, net, &p);
+    lbdrn_geom gx = g;
+    gx.msb_max = 1;                     // (the workspace is sized before the image's maximum is known to the caller's struct)
+    const bool x = make_plan(gx, net, &q, true, true) && q.x16;
+    return align_up((size_t)std::max(p.pack_floats, x ? q.pack_floats : 0) * 4, 256);
+}
+
 size_t mfma_apply_workspace(const lbdrn_geom& g, const lbdrn_net& net)
 {
     ApplyPlan p;
     if (!make_plan(g, net, &p)) return wapply_workspace(g, net);
-    return align_up((size_t)p.pack_floats * 4, 256) + align_up(MFMA_PARTIALS * sizeof(double), 256);
+    return apply_pack_bytes(g, net) + align_up(MFMA_PARTIALS * sizeof(double), 256) + 256;
 }
 
 // ------------------------------------------------------------------ weight packing
 
 // params (state_dict order) -> fragment order; one thread per packed float
+// max |W_0| (x16: fixes the power of two that brings the weights into fp16's range); one block
+__global__ void __launch_bounds__(256) k_w0_absmax(const float* __restrict__ params, int n, float* __restrict__ out)
+{
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int e = threadIdx.x; e < n; e += 256) m = fmaxf(m, fabsf(params[e]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = red[0];
+}
+
+// x16: the power of two s with max |W_0| 2^s < 2^15 (fp16 holds every scaled weight; 0 for an all-zero layer)
+__device__ __forceinline__ int x16_shift(float amax)
+{
+    if (!(amax > 0.0f) || !(amax < 3.0e38f)) return 0;
+    int ex;
+    (void)frexpf(amax, &ex);      // amax = m 2^ex, 0.5 <= m < 1
+    return 15 - ex;
+}
+
 __global__ void __launch_bounds__(256)
-    k_pack_apply(const float* __restrict__ params, lbdrn_net net, ApplyPlan p, int P, int C, float* __restrict__ out)
+    k_pack_apply(const float* __restrict__ params, lbdrn_net net, ApplyPlan p, int P, int C, int msb_max, const float* __restrict__ amax,
+                 float* __restrict__ out)
 {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.pack_floats) return;
     const int NT = p.NT, half = net.bc / 2;
     float v = 0.0f;
+    if (p.x16 && e < p.off_wh) {
+        // layer 0, exact-operand f16 (layer0_pair_x16): [channel pair][MFMA m][piece][lane][tile][8 halfs]; this thread: two
+        // halfs.  Lane (row i = lane & 31, half h = lane >> 5) of MFMA m holds W_0[neuron(i, tile)][channel cp + h C/2][window
+        // positions 8 m .. 8 m + 7, the centre left out], scaled by 2^s and cut into three fp16 pieces whose sum IS the float32
+        // weight (3 x 11 bits of mantissa)
+        const int j = e & 3, q4 = e >> 2;
+        const int t = q4 % NT, lane = (q4 / NT) % 64, rest = q4 / (NT * 64);
+        const int piece = rest % X16_PIECES, m = (rest / X16_PIECES) % p.M16, cp = rest / (X16_PIECES * p.M16);
+        const int s2 = p.ncolor / C, cen = s2 / 2, sh = x16_shift(*amax);
+        const int neuron = tile_row_to_neuron(lane & 31) + 32 * t, ch = cp + (lane >> 5) * (C / 2);
+        _Float16 hv[2];
+        for (int u = 0; u < 2; ++u) {
+            const int pos = 8 * m + 2 * j + u, r = pos + (pos >= cen ? 1 : 0);
+            const float w = ldexpf(params[(int64_t)neuron * net.F + ch * s2 + r], sh);
+            const _Float16 hi = (_Float16)w;
+            const float r1 = w - (float)hi;
+            const _Float16 mid = (_Float16)r1;
+            const float r2 = r1 - (float)mid;
+            hv[u] = piece == 0 ? hi : piece == 1 ? mid : (_Float16)r2;
+        }
+        f16x2 pk = {hv[0], hv[1]};
+        out[e] = __builtin_bit_cast(float, pk);
+        return;
+    }
+    if (e >= p.off_scale) {   // x16: acc * this = the pre-activation's sum (acc = sum of (w 2^s) x integer difference)
+        out[e] = (p.x16 && e == p.off_scale) ? ldexpf(1.0f, -x16_shift(*amax)) / (float)msb_max : 0.0f;
+        return;
+    }
     if (e < p.off_wh) {  // layer 0: [S0][64][NT]
         int t = e % NT, lane = (e / NT) % 64, s = e / (NT * 64);
         int k = 2 * s + (lane >> 5);
@@ -186,7 +263,9 @@ __global__ void __launch_bounds__(256)
 
 // ------------------------------------------------------------------ the fused kernel
 
-enum ApplyMode { MODE_DECODE = 0, MODE_EVAL = 1, MODE_EVAL_FAST = 2 };   // _FAST: the evaluation pass in the tolerance arithmetic (lbdrn_math.hpp)
+enum ApplyMode { MODE_DECODE = 0, MODE_EVAL = 1, MODE_EVAL_FAST = 2,   // _FAST: the evaluation pass in the tolerance arithmetic (lbdrn_math.hpp)
+                 MODE_EVAL_X16 = 3 };   // _FAST with the colour features of layer 0 on the f16 matrix pipe, exact operands (opt-in)
+__host__ __device__ constexpr bool mode_fast(int mode) { return mode == MODE_EVAL_FAST || mode == MODE_EVAL_X16; }
 
 struct ApplyArgs {
     lbdrn_geom g;
@@ -260,12 +339,55 @@ __device__ __forceinline__ void layer0_pair(f32x16 (&acc)[NT], const float* wc, 
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// Layer 0 over the colour features on the f16 matrix pipe, operands EXACT (MODE_EVAL_X16; ApplyPlan::x16).  A relative colour
+// feature is (msb_nbr - msb_ctr) / max: the numerator an integer of at most 11 bits -- exactly an fp16 --, and a float32
+// weight is exactly the sum of three fp16 pieces once a power of two has brought it into range (k_pack_apply).  So
+//     sum_k W[n][k] x[k]  =  (2^-s / max)  sum_pieces sum_k piece[n][k] * int[k]
+// with every product exact (11 x 11 bits) and the sums taken in float32 by v_mfma_f32_32x32x16_f16: the same real numbers as
+// the float32 MFMA of layer0_pair, with fewer roundings (the reference rounds nbr / max, ctr / max and their difference; this
+// rounds none of them), at 3/16 of its matrix-pipe cycles.  Lane half h walks channel c + h C/2 as in layer0_pair; one MFMA
+// takes eight window positions of both channels (k = 8 h + i).  tp: the STAGED INTEGERS of this lane's pixel (tile holds
+// float(msb), not msb / max, in this mode); wc: the pair's first fragment + lane NT 4 floats.
+template <int NT, int D>
+__device__ __forceinline__ void layer0_pair_x16(f32x16 (&acc)[NT], const float* wc, const float* tp)
+{
+    constexpr int side = 2 * D + 1, S2 = side * side, CEN = D * side + D, SW = TILE_W + 2 * D, RS = S2 - 1, M = RS / 8;
+    static_assert(RS % 8 == 0, "(2D+1)^2 - 1 = 4 D (D+1)");
+    const float cen = tp[D * SW + D];
+    float bq[RS];
+#pragma unroll
+    for (int r = 0; r < S2; ++r) {
+        if (r == CEN) continue;
+        bq[r - (r > CEN ? 1 : 0)] = tp[(r / side) * SW + (r % side)] - cen;     // an integer in [-2047, 2047]: exact
+    }
+    f16x8 b[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f16x2 pk = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(bq[8 * m + 2 * j], bq[8 * m + 2 * j + 1]));   // (exact: integers)
+            b[m][2 * j] = pk[0];
+            b[m][2 * j + 1] = pk[1];
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int pc = 0; pc < X16_PIECES; ++pc) {
+            const float4* ap = reinterpret_cast<const float4*>(wc + (size_t)((m * X16_PIECES + pc) * 64) * NT * 4);
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ap[tt]), b[m], acc[tt], 0, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // hidden activation of one accumulator entry.  RELU: z where z > 0, else 0 (torch.nn.ReLU: the same in every arithmetic)
 template <int MODE, bool RELU>
 __device__ __forceinline__ float apply_hidden_act(float z)
 {
     if constexpr (RELU) return z > 0.0f ? z : 0.0f;
-    else return MODE == MODE_EVAL_FAST ? fast_sin(30.0f * z) : siren_act(z);
+    else return mode_fast(MODE) ? fast_sin(30.0f * z) : siren_act(z);
 }
 
 template <int NT, int MODE, bool RELU>
@@ -355,13 +477,13 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                     }
                     // (the fast evaluation pass is internal to a fit, whose MSB plane IS img >> K: one plane read per pass
                     //  instead of two; the API's canonical pass and the decode pass read the plane they are given)
-                    raw[u] = MODE == MODE_EVAL_FAST ? (unsigned short)(A.img[(int64_t)c * HW + (int64_t)yy * g.W + xx] >> g.K)
-                                                    : A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx];
+                    raw[u] = mode_fast(MODE) ? (unsigned short)(A.img[(int64_t)c * HW + (int64_t)yy * g.W + xx] >> g.K)
+                                             : A.msb[(int64_t)c * HW + (int64_t)yy * g.W + xx];
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
                     const int e = base + u * APPLY_THREADS + tid;
-                    if (e < total) tile[e] = (float)raw[u] / maxf;
+                    if (e < total) tile[e] = MODE == MODE_EVAL_X16 ? (float)raw[u] : (float)raw[u] / maxf;   // (x16: the integers themselves)
                 }
             }
         }
@@ -406,7 +528,32 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                     acc[tt][q4 * 4 + 0] = b4.x; acc[tt][q4 * 4 + 1] = b4.y;
                     acc[tt][q4 * 4 + 2] = b4.z; acc[tt][q4 * 4 + 3] = b4.w;
                 }
-            for (int s = 0; s < P; ++s) {  // positional features, k = 2s+h < 2P
+            if constexpr (MODE == MODE_EVAL_X16) {
+                // exact-operand f16 layer 0 (the plan guarantees P == 0, relative colours, D in 1..3): the accumulator starts at
+                // zero, collects sum (w 2^s) x integer, and becomes the pre-activation as fma(acc, 2^-s / max, bias)
+                f32x16 bias0[NT];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt) {
+                    bias0[tt] = acc[tt];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+                }
+                const int plane = p.SH * p.SW;
+                const float* tp = tile + h * (C / 2) * plane + ly * p.SW + lx + j;
+                const float* wc = w0 + (size_t)lane * NT * 4;
+                const size_t wstep = (size_t)p.M16 * X16_PIECES * 64 * NT * 4;
+                for (int c = 0; c < C / 2; ++c, tp += plane, wc += wstep) {
+                    if (D == 1) layer0_pair_x16<NT, 1>(acc, wc, tp);
+                    else if (D == 2) layer0_pair_x16<NT, 2>(acc, wc, tp);
+                    else layer0_pair_x16<NT, 3>(acc, wc, tp);
+                }
+                const float cs = lds[p.off_scale];
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tt][r] = fmaf(acc[tt][r], cs, bias0[tt][r]);
+            }
+            for (int s = 0; s < (MODE == MODE_EVAL_X16 ? 0 : P); ++s) {  // positional features, k = 2s+h < 2P
                 int k = 2 * s + h;
                 float b = (k < P) ? rowt[ly * P + k] : colt[(lx + j) * P + (k - P)];
                 float a[NT];
@@ -415,7 +562,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
                 for (int tt = 0; tt < NT; ++tt)
                     acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tt], b, acc[tt], 0, 0, 0);
             }
-            bool paired = false;
+            bool paired = MODE == MODE_EVAL_X16;
             if constexpr (MODE == MODE_EVAL_FAST) {
                 if (p.pair) {
                     paired = true;
@@ -538,7 +685,7 @@ __global__ void __launch_bounds__(APPLY_THREADS) k_apply_mfma(ApplyArgs A)
             for (int r = 0; r < 16; ++r) {
                 const int ch = acc_row(r, h);
                 if (r < nreg && ch < C && inside) {
-                    float yv = MODE == MODE_EVAL_FAST ? fast_sigmoid(o[r]) : canon_sigmoid(o[r]);
+                    float yv = mode_fast(MODE) ? fast_sigmoid(o[r]) : canon_sigmoid(o[r]);
                     if (MODE == MODE_DECODE) {
                         float rr = __builtin_rintf(yv * scale);  // torch.round, decode.py:131
                         int base = (int)pre[r] << g.K;             // decode.py:134
@@ -664,6 +811,7 @@ static int run_wapply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const
                       double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
 {
     WApplyArgs A;
+    if (mode == MODE_EVAL_X16) mode = MODE_EVAL_FAST;     // (the streaming kernel has no exact-operand layer 0)
     if (!make_wapply_plan(g, net, &A.p, mode == MODE_EVAL_FAST)) {
         set_error("shape not supported by the MFMA apply kernels");
         return LBDRN_E_UNSUPPORTED;
@@ -719,15 +867,22 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
                      double* sse, void* ws, size_t ws_bytes, bool background, hipStream_t s)
 {
     ApplyArgs A;
-    if (!make_plan(g, net, &A.p, mode == MODE_EVAL_FAST))   // too wide for LDS-resident weights: the streaming kernel (apply_wide.inc)
+    if (!make_plan(g, net, &A.p, mode_fast(mode), mode == MODE_EVAL_X16))   // too wide for LDS-resident weights: the streaming kernel (apply_wide.inc)
         return run_wapply(g, net, mode, img, msb, params, out, y_out, sse, ws, ws_bytes, background, s);
+    if (mode == MODE_EVAL_X16 && !A.p.x16) mode = MODE_EVAL_FAST;    // (a hint: the shape or the image does not qualify, the pass is the fast one)
     if (!ws || ws_bytes < mfma_apply_workspace(g, net)) {
         set_error("apply workspace too small: %zu < %zu", ws_bytes, mfma_apply_workspace(g, net));
         return LBDRN_E_WORKSPACE;
     }
     float* packed = (float*)ws;
-    double* partial = (double*)((char*)ws + align_up((size_t)A.p.pack_floats * 4, 256));
-    k_pack_apply<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, g.P, g.C, packed);
+    const size_t pack_bytes = apply_pack_bytes(g, net);
+    double* partial = (double*)((char*)ws + pack_bytes);
+    float* amax = (float*)((char*)ws + pack_bytes + align_up(MFMA_PARTIALS * sizeof(double), 256));
+    if (A.p.x16) {
+        k_w0_absmax<<<1, 256, 0, s>>>(params, net.bc * net.F, amax);
+        LBDRN_LAUNCH_CHECK();
+    }
+    k_pack_apply<<<(A.p.pack_floats + 255) / 256, 256, 0, s>>>(params, net, A.p, g.P, g.C, g.msb_max, amax, packed);
     LBDRN_LAUNCH_CHECK();
     A.g = g; A.net = net; A.packed = packed; A.msb = msb; A.img = img; A.out = out; A.y_out = y_out;
     A.partial = partial;
@@ -750,7 +905,9 @@ static int run_apply(const lbdrn_geom& g, const lbdrn_net& net, int mode, const 
            : A.p.NT == 2 ? launch_apply<2, MODE_DECODE>(A, grid, s)
                          : launch_apply<4, MODE_DECODE>(A, grid, s);
     } else {
-        rc = mode == MODE_EVAL_FAST
+        rc = mode == MODE_EVAL_X16
+                 ? (A.p.NT == 1 ? launch_apply<1, MODE_EVAL_X16>(A, grid, s, background) : launch_apply<2, MODE_EVAL_X16>(A, grid, s, background))
+             : mode == MODE_EVAL_FAST
                  ? (A.p.NT == 1 ? launch_apply<1, MODE_EVAL_FAST>(A, grid, s, background)
                     : A.p.NT == 2 ? launch_apply<2, MODE_EVAL_FAST>(A, grid, s, background)
                                   // bc = 128: the tolerance arithmetic's extra operands spill at two waves per SIMD (88 registers,
@@ -786,9 +943,9 @@ int mfma_decode(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* msb, 
 
 int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                   const uint16_t* msb, const float* params, double* sse, void* ws, size_t ws_bytes,
-                  bool background, bool fast, hipStream_t s)
+                  bool background, bool fast, bool x16, hipStream_t s)
 {
-    return run_apply(g, net, fast ? MODE_EVAL_FAST : MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes,
+    return run_apply(g, net, fast ? (x16 ? MODE_EVAL_X16 : MODE_EVAL_FAST) : MODE_EVAL, img, msb, params, nullptr, nullptr, sse, ws, ws_bytes,
                      background, s);
 }
 

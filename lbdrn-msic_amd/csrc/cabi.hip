@@ -182,11 +182,12 @@ int lbdrn_eval_sse(const lbdrn_geom* g, const lbdrn_net* net, const uint16_t* im
     LBDRN_REQUIRE(img && msb && params && sse, "img, msb, params and sse must not be null");
     NEED_DEVICE();
     const bool background = (path & LBDRN_EVAL_BACKGROUND) != 0, fast = (path & LBDRN_EVAL_FAST) != 0;
-    path &= ~(LBDRN_EVAL_BACKGROUND | LBDRN_EVAL_FAST);
+    const bool x16 = fast && (path & LBDRN_EVAL_X16) != 0;
+    path &= ~(LBDRN_EVAL_BACKGROUND | LBDRN_EVAL_FAST | LBDRN_EVAL_X16);
     bool use_mfma = false;
     if (int rc = pick_apply(g, net, path, &use_mfma)) return rc;
     if (use_mfma)
-        return mfma_eval_sse(*g, *net, img, msb, params, sse, workspace, workspace_bytes, background, fast,
+        return mfma_eval_sse(*g, *net, img, msb, params, sse, workspace, workspace_bytes, background, fast, x16,
                              (hipStream_t)stream);
     return generic_eval_sse(*g, *net, img, msb, params, sse, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -87,7 +87,7 @@ int mfma_decode(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* msb, 
                 uint16_t* out, float* y_out, void* ws, size_t ws_bytes, hipStream_t s);
 int mfma_eval_sse(const lbdrn_geom& g, const lbdrn_net& net, const uint16_t* img,
                   const uint16_t* msb, const float* params, double* sse, void* ws, size_t ws_bytes,
-                  bool background, bool fast, hipStream_t s);
+                  bool background, bool fast, bool x16, hipStream_t s);
 
 int mfma_train_epoch_group(int count, const lbdrn_geom& g, const lbdrn_net& net, const int64_t* const* perm, int64_t n,
                            int bs, float* const* params, float* const* m, float* const* v, int64_t step0, double lr,

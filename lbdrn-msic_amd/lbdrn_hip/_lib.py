@@ -10,6 +10,7 @@ ABI_VERSION = 2           # LBDRN_ABI_VERSION of include/lbdrn_hip.h this bindin
 PATH_AUTO, PATH_GENERIC, PATH_MFMA = 0, 1, 2
 EVAL_BACKGROUND = 0x200   # hint OR'ed into `path` of lbdrn_eval_sse
 EVAL_FAST = 0x400         # the per-epoch ranking pass in the tolerance arithmetic (lbdrn_hip.h)
+EVAL_X16 = 0x1000         # with EVAL_FAST, opt-in: layer 0's colour features on the f16 matrix pipe, operands exact (lbdrn_hip.h)
 TRAIN_ALONE = 0x800       # hint OR'ed into `path` of lbdrn_train_epoch: nothing else in flight on the device (lbdrn_hip.h)
 
 

@@ -111,6 +111,12 @@ def fast_evaluation():
     return os.environ.get("LBDRN_EVAL_CANONICAL") != "1"
 
 
+def exact16_evaluation():
+    """LBDRN_EVAL_X16=1 (opt-in, off by default): the fast evaluation passes take layer 0's colour features through the f16
+    matrix pipe with exact operands (lbdrn_hip.h: LBDRN_EVAL_X16) where the shape and the image qualify."""
+    return os.environ.get("LBDRN_EVAL_X16") == "1"
+
+
 def alone_streams_fit_queues():
     """A fit alone in its process uses three streams at a time: the caller's, one fit stream for the background passes,
     the permutation side stream."""
@@ -363,7 +369,7 @@ def fit_device(img_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
                     if cal_events is not None and e == cal_epoch:
                         cal_events[0].record()
                     sse = ops.eval_sse(geom, net, img_d, msb_d, snaps[k], path, apply_ws, background=background,
-                                       fast=fast_evaluation())   # a9
+                                       fast=fast_evaluation(), x16=exact16_evaluation())   # a9
                     if cal_events is not None and e == cal_epoch:
                         cal_events[1].record()
                     mses[k:k + 1].copy_((sse / float(N * C)).float())
@@ -445,7 +451,7 @@ def fit_group(imgs_d, K, D, base_channel, num_layers, lr, batch_size, epochs, va
             k = eval_epochs.index(e)
             for f, out in zip(st, outs):
                 f["snaps"][k].copy_(f["params"])
-                sse = ops.eval_sse(f["geom"], net, f["img"], f["msb"], f["snaps"][k], path, f["aws"], fast=fast_evaluation())   # a9
+                sse = ops.eval_sse(f["geom"], net, f["img"], f["msb"], f["snaps"][k], path, f["aws"], fast=fast_evaluation(), x16=exact16_evaluation())   # a9
                 f["mses"][k:k + 1].copy_((sse / float(N * C)).float())
                 out.evaluated.append(e)
     for f, out in zip(st, outs):

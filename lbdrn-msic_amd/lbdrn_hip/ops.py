@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import EVAL_BACKGROUND, EVAL_FAST, TRAIN_ALONE, Geom, Net, PATH_AUTO, check, lib
+from ._lib import EVAL_BACKGROUND, EVAL_FAST, EVAL_X16, TRAIN_ALONE, Geom, Net, PATH_AUTO, check, lib
 
 
 def _call(fn, ref, *args):
@@ -143,11 +143,12 @@ def decode_fused(geom, net, msb, params, want_y=False, path=PATH_AUTO, ws=None):
     return (out, y) if want_y else out
 
 
-def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None, background=False, fast=False):
+def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None, background=False, fast=False, x16=False):
     """Whole-image sum of squared error as a device float64 scalar tensor (no sync).
     background: launch on half as many workgroups (LBDRN_EVAL_BACKGROUND, lbdrn_hip.h); same sum bit for bit.
     fast: the epoch-ranking pass in the training step's arithmetic (LBDRN_EVAL_FAST: within 1e-6 relative of the
-    canonical sum, a fifth less time); the default is the canonical arithmetic of the decode kernels."""
+    canonical sum, a fifth less time); the default is the canonical arithmetic of the decode kernels.
+    x16 (with fast; opt-in): layer 0's colour features on the f16 matrix pipe with exact operands (LBDRN_EVAL_X16)."""
     _need_cuda(img, msb, params)
     img = _u16(img.contiguous())
     msb = _u16(msb.contiguous())
@@ -156,7 +157,8 @@ def eval_sse(geom, net, img, msb, params, path=PATH_AUTO, ws=None, out=None, bac
     ws = ws or ApplyWorkspace(geom, net, msb.device)
     _call(lib().lbdrn_eval_sse, msb, ctypes.byref(geom.c), ctypes.byref(net), _ptr(img), _ptr(msb),
                                _ptr(params), _ptr(sse), _ptr(ws.buf), ws.nbytes,
-                               path | (EVAL_BACKGROUND if background else 0) | (EVAL_FAST if fast else 0))
+                               path | (EVAL_BACKGROUND if background else 0) | (EVAL_FAST if fast else 0) |
+                               (EVAL_X16 if (fast and x16) else 0))
     return sse
 
 

@@ -912,3 +912,62 @@ def test_minibatches_whose_slabs_pass_2_gib_take_the_generic_step(dev):
     for a, b in zip(*got):
         assert np.array_equal(a, b)
     assert np.isfinite(got[0][3].view(np.float32)).all()
+
+
+def test_exact_operand_f16_layer0_of_the_evaluation_pass(golden, dev):
+    """LBDRN_EVAL_X16 (opt-in): with the flag the fast evaluation pass multiplies layer 0's colour features on the
+    f16 matrix pipe -- integer window differences x W_0 in three fp16 pieces, every product exact, float32 sums.  Its float64
+    sum must sit as close to the canonical pass as the fast pass does (1e-6 relative; measured ~1e-9), be reproducible and
+    the same on a background launch; where the shape or the image does not qualify (MSB values above 2047, positional features,
+    absolute colours, bc = 256) the flag is ignored and the sum is the fast pass's, bit for bit; and a fit that ranks its epochs
+    with it picks the same epoch and ends on the same weights."""
+    rng = np.random.default_rng(8)
+    def sums(img, K, D, bc, nl, cfg, params):
+        C, H, W = img.shape
+        img_d = ops.to_device_u16(img, dev)
+        msb_d, mx = ops.split_bits(img_d, K)
+        geom = ops.FeatureGeometry(C, H, W, K, D, mx, cfg, dev)
+        net = ops.make_net(cfg.feature_dim(C, D), bc, C, nl, cfg.act)
+        p = torch.from_numpy(params(cfg.feature_dim(C, D))).to(dev)
+        canon = float(ops.eval_sse(geom, net, img_d, msb_d, p).item())
+        fast = float(ops.eval_sse(geom, net, img_d, msb_d, p, fast=True).item())
+        x = [float(ops.eval_sse(geom, net, img_d, msb_d, p, fast=True, x16=True, background=b).item()) for b in (False, False, True)]
+        assert x[0] == x[1] == x[2]
+        return canon, fast, x[0], mx
+    # qualifying shapes: the trained weights of the learnable rasters (8 and 4 bands), random and huge weights, D = 1 / 3, ReLU
+    for tag in ("bc64", "bands4"):
+        G = golden["rasters_learn_" + tag]
+        canon, fast, x16, mx = sums(G["img"], 5, 2, 64, 2, FeatCfg(), lambda F: G["params"])
+        assert mx <= 2047 and x16 != fast and abs(x16 - canon) <= 1e-6 * canon, (tag, x16, fast, canon)
+    for (C, H, W, K, D, bc, nl, act, gain) in [(8, 70, 150, 5, 2, 64, 2, "sine", 1.0), (4, 33, 65, 5, 1, 64, 1, "sine", 40.0),
+                                                (2, 40, 70, 6, 3, 32, 2, "sine", 3.0), (6, 31, 64, 5, 2, 64, 2, "relu", 30.0),
+                                                (8, 48, 64, 9, 2, 64, 2, "sine", 1e-4)]:
+        img = rng.integers(0, 65536, (C, H, W)).astype(np.uint16)
+        cfg = FeatCfg(activation=act)
+        canon, fast, x16, mx = sums(img, K, D, bc, nl, cfg, lambda F: _params(rng, F, bc, C, nl) * np.float32(gain))
+        assert mx <= 2047 and (x16 != fast or gain < 1.0), (C, D, bc)      # (weights of 1e-4: differences below a float32 ulp of y vanish)
+        assert abs(x16 - canon) <= 1e-6 * canon, (C, D, bc, act, x16, canon)
+    # not qualifying: the flag changes nothing
+    for (img, K, bc, cfg) in [(rng.integers(0, 65536, (8, 40, 70)).astype(np.uint16), 3, 64, FeatCfg()),                       # msb up to 8191
+                              (synthetic_tile(2, 8, 40, 70), 5, 64, FeatCfg(True, True, 1.4, 12, True, True)),                # positional features
+                              (synthetic_tile(2, 8, 40, 70), 5, 64, FeatCfg(False, False, 1.4, 12, True, False)),             # absolute colours
+                              (synthetic_tile(2, 8, 40, 70), 5, 256, FeatCfg())]:                                              # the streaming kernel
+        canon, fast, x16, mx = sums(img, K, 2, bc, 2, cfg, lambda F: _params(rng, F, bc, 8, 2))
+        assert x16 == fast, (K, bc, vars(cfg))
+    # whole fits ranked with it
+    for img, epochs, bs in ((golden["rasters_learn_bc64"]["img"], 12, 8192), (golden["rasters_learn_bands4"]["img"], 6, 8192),
+                            (synthetic_tile(31, 8, 96, 128), 10, 1024)):
+        img_d = ops.to_device_u16(img, dev)
+        fits = []
+        for flag in ("0", "1"):
+            os.environ["LBDRN_EVAL_X16"] = flag
+            try:
+                torch.manual_seed(19920517)
+                fits.append(codec.fit_device(img_d, 5, 2, 64, 2, 1e-3, bs, epochs))
+            finally:
+                os.environ.pop("LBDRN_EVAL_X16", None)
+        a, b = fits
+        assert torch.equal(a.best_params.view(torch.int32), b.best_params.view(torch.int32)), epochs
+        assert torch.equal(a.mse_log[:, 1], b.mse_log[:, 1]), epochs
+        np.testing.assert_allclose(a.mse_log[:, 0].cpu().numpy(), b.mse_log[:, 0].cpu().numpy(), rtol=1e-6)
+        # (measured: the float32 MSEs of the epochs come out IDENTICAL -- the two passes' float64 sums differ by parts in 1e10)
