@@ -143,8 +143,8 @@ constexpr int MFMA_PARTIALS = 1024;
 // the packed weights of the largest of a shape's plans | the SSE partials | one float: max |W_0| (x16)
 static size_t apply_pack_bytes(const lbdrn_geom& g, const lbdrn_net& net)
 {
-    ApplyPlan p, q;
-    make_plan(g, net, &p);
+    ApplyPlan p{}, q{};
+    if (!make_plan(g, net, &p)) return 0;
     lbdrn_geom gx = g;
     gx.msb_max = 1;                     // (the workspace is sized before the image's maximum is known to the caller's struct)
     const bool x = make_plan(gx, net, &q, true, true) && q.x16;
