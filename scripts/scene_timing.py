@@ -3,7 +3,8 @@ of the GF6-WFI scenes of the reference's tables -- throu
 -sr 1 (one 36 M-pixel fit: a 30 GB row matrix, ten 288 MB permutations from lbdrn_randperm's n > 2048^2 path) and -sr 3
 (nine 2000 x 2000 tiles, codec.fit_many sizing its fits in flight against the free memory).  Prints one JSON record per
 run: wall times, the device memory high-water mark, bytes, PSNR, whether the high bits came back exact.
-usage: scene_timing.py [side=6000] [epochs=10] [sr ...=1 3]"""
+usage: scene_timing.py [side=6000] [epochs=10] [sr ...=1 3]       LBDRN_SCENE_BANDS=4: the 4-band scenes of the reference's list
+(GF-2, GF6-PMS: 9 of the 13 images of run.sh:14-28; side 7550 ~ a 57 M-pixel GF-2 scene)"""
 import json, os, re, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lbdrn-msic_amd"))
@@ -16,7 +17,7 @@ from lbdrn_hip.synth import synthetic_tile
 side = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 srs = [int(x) for x in sys.argv[3:]] or [1, 3]
-C, K = 8, 5
+C, K = int(os.environ.get("LBDRN_SCENE_BANDS", "8")), 5
 dev = torch.device("cuda:0")
 with tempfile.TemporaryDirectory() as d:
     warm = os.path.join(d, "warm.npy")
