@@ -502,3 +502,58 @@ def test_hidden_activation_switch_host_side():
     assert a.hip_net().act == ops.ACT_SINE and b.hip_net().act == ops.ACT_RELU
     assert not LBDRNModel(200, 64, 8, 2, activation=torch.nn.Tanh())._fused_ok
     assert not LBDRNModel(200, 64, 8, 2, activation=torch.nn.ReLU(), final_activation=torch.nn.Identity())._fused_ok
+
+
+def test_lone_fit_schedule_calibration_logic():
+    """codec._calibrated_head (host logic only: stand-in events): the model's guess until a fit's events have completed, then
+    head x t_pass / t_head kept within [guess / 2, 2 guess] and within the epoch; events that have not completed yet are left for
+    a later fit (never waited for)."""
+    from lbdrn_hip import codec
+
+    class Ev:
+        def __init__(self, t, done=True):
+            self.t, self.done = t, done
+
+        def query(self):
+            return self.done
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    key = ("test", 1)
+    codec._HEAD_MEASURED.pop(key, None)
+    codec._HEAD_PENDING.pop(key, None)
+    assert codec._calibrated_head(key, 137, 512) == 137                     # nothing measured: the guess
+    codec._HEAD_PENDING[key] = ((Ev(0.0), Ev(3.0, done=False), Ev(0.0), Ev(2.0)), 137)
+    assert codec._calibrated_head(key, 137, 512) == 137 and key in codec._HEAD_PENDING     # pass still running: not waited for
+    codec._HEAD_PENDING[key] = ((Ev(0.0), Ev(3.0), Ev(0.0), Ev(2.0)), 100)  # the pass lasted 1.5 x the head
+    assert codec._calibrated_head(key, 137, 512) == 150 and key not in codec._HEAD_PENDING
+    codec._HEAD_PENDING[key] = ((Ev(0.0), Ev(30.0), Ev(0.0), Ev(1.0)), 150)  # absurd ratio: clamped to twice the guess
+    assert codec._calibrated_head(key, 137, 512) == 274
+    codec._HEAD_PENDING[key] = ((Ev(0.0), Ev(0.1), Ev(0.0), Ev(9.0)), 274)   # ... and to half of it
+    assert codec._calibrated_head(key, 137, 512) == 68
+    assert codec._calibrated_head(key, 137, 40) == 40                        # never more than the epoch has
+    assert codec.head_calibration()[key] == 68
+    codec._HEAD_MEASURED.pop(key, None)
+
+
+def test_base_payloads_coded_ahead_equal_the_ones_coded_afterwards():
+    """encode.BasePayloadsAhead (host threads, no GPU): the JPEG 2000 payloads of an image's tiles coded on a background thread
+    are the bytes container.encode_base gives for tile >> K with the reference's dtype rule (LBDRNdataset.py:100); an error in
+    the thread is raised where the payload is asked for."""
+    from lbdrn_hip import container, jp2
+    if not jp2.available():
+        pytest.skip("liblbdrn_jp2.so not built (OpenJPEG absent)")
+    import encode
+    rng = np.random.default_rng(5)
+    tiles = [rng.integers(0, 10000, (4, 40, 56)).astype(np.uint16), rng.integers(0, 6000, (2, 33, 21)).astype(np.uint16)]
+    ahead = encode.BasePayloadsAhead(tiles, 5)
+    for k in (1, 0):
+        msb = tiles[k] >> 5
+        msb = msb.astype(np.uint8) if int(msb.max()) <= 255 else msb
+        want = container.encode_base(msb, codec="jp2")
+        got = ahead.take(k)
+        assert got == want and np.array_equal(container.decode_base(got), msb) and container.decode_base(got).dtype == msb.dtype
+    bad = encode.BasePayloadsAhead([np.zeros((2, 3), np.float32)], 5)       # (not a raster of integers: the shift raises in the thread)
+    with pytest.raises(Exception):
+        bad.take(0)
