@@ -713,6 +713,31 @@ def test_bench_prints_one_json_line_with_the_contract_keys(dev):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert str(c["cores"]) in c["form_B_by_threads"] and c["vectorised_form_B"] == max(c["form_B_by_threads"].values())
+    # round 6: the tile as an equation -- its terms come from the line's own figures and add up to the measured tile
+    a = d["accounting"]
+    launches = 3 * ((192 * 256 + 2047) // 2048) / d["config"]["tiles_per_launch"]
+    assert a["training_launches_per_tile"] == launches and abs(a["training_ms"] - launches * r["kernel_us"] * 1e-3) < 0.02
+    assert abs(a["evaluation_passes_ms"] - 3 * r["apply_pass_ms"]) < 0.02 and abs(a["measured_ms_per_tile"] - d["ms_per_step"]) < 0.02
+    assert abs(a["training_ms"] + a["evaluation_passes_ms"] + a["decode_ms"] + a["rest_ms"] - a["measured_ms_per_tile"]) < 0.05
+    # ... and the opt-in evaluation arithmetic is timed beside the one the fits ran, never instead of it
+    assert r["apply_pass_x16_ms_opt_in"] > 0 and "LBDRN_EVAL_X16" not in r["apply_pass"]
+
+
+def test_bench_four_band_run_has_its_own_roofline(dev):
+    """`bench.py --bands 4` (the reference's majority shape) on a small tile: the line names the workload, the fits of the timed
+    region equal the lone fit bit for bit, FLOPs are counted over the 96 features the step multiplies."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--bands", "4", "--steps", "4", "--warmup", "2", "--height", "192",
+                          "--width", "256", "-bs", "2048", "-e", "3", "--no-cpu-baseline", "--repeats", "1"],
+                         check=True, env=env, capture_output=True, text=True, timeout=900).stdout
+    d = json.loads([ln for ln in out.splitlines() if ln.strip()][-1])
+    assert "4-band" in d["config"]["workload"] and d["timed_equals_lone"] is True and d["config"]["tiles_per_launch"] == 2
+    r = d["roofline"]
+    assert r["features_multiplied"] == 96 and r["fits_per_launch"] == 2 and r["kernel_us"] > 0 and 0 < r["frac"] <= r["frac_live"] + 1e-9
+    assert r["flop_per_launch"] == 2 * 2048 * (3 * 2 * (96 * 64 + 64 * 64 + 64 * 4) - 2 * 96 * 64)
 
 
 def test_the_reference_scene_size_through_the_clis(dev, tmp_path):
