@@ -550,7 +550,10 @@ def accounting(a, roof, fits_per_launch, ms_per_tile, decode_ms):
         tile ~= (steps / fits per launch) x training launch  +  evaluation passes  +  decode pass  +  rest
     `training launch` = the launch's own duration (roofline.kernel_us: the launch sequence alone), `rest` = what is left of
     the measured tile: the row build, the permutations, reduce / Adam launches that found no room beside another chain's
-    training launch, ramps.  A faster training launch ALONE moves the tile only by its share of this sum."""
+    training launch, ramps.  An identity at the measured operating point, not a law: timing-only builds
+    (profiles/r06_bounds_in_flight.txt) show the tile sitting where three bounds coincide -- the matrix pipe (this launch's own
+    duration), the memory system under two chains of launches (gradient slabs, gathered rows) and the latency of a chain's step --,
+    so a faster training launch ALONE moves the tile by far less than its term here (-18 % of the launch: -2 % of the tile)."""
     px = a.height * a.width
     steps = a.epochs * ((px + a.bs - 1) // a.bs)
     launches = steps / max(fits_per_launch, 1)
@@ -561,7 +564,9 @@ def accounting(a, roof, fits_per_launch, ms_per_tile, decode_ms):
     return {"training_launches_per_tile": launches, "training_ms": round(train_ms, 2), "evaluation_passes_ms": round(eval_ms, 2),
             "decode_ms": round(decode_ms, 2), "rest_ms": round(ms_per_tile - known, 2), "measured_ms_per_tile": round(ms_per_tile, 2),
             "training_share": round(train_ms / ms_per_tile, 3),
-            "equation": "measured_ms_per_tile = training_launches_per_tile x roofline.kernel_us + epochs x roofline.apply_pass_ms + decode_ms + rest_ms"}
+            "equation": "measured_ms_per_tile = training_launches_per_tile x roofline.kernel_us + epochs x roofline.apply_pass_ms + decode_ms + rest_ms",
+            "note": "an identity at this operating point, where the matrix pipe, the memory system (slabs, rows) and a chain's step latency "
+                    "bound the tile together: profiles/r06_bounds_in_flight.txt, DESIGN.md 4.0"}
 
 
 def launch_ranks(a):
